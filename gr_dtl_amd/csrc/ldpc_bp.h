@@ -1,0 +1,49 @@
+// ldpc_bp.h -- device-side LDPC sum-product decoder (kernel K10) for gfx950.
+#pragma once
+
+#include "dtl_common.h"
+#include "ldpc_code.h"
+
+namespace dtl {
+
+// Where one codeword's on-air soft bits live and where its decoded bits go
+// (transport-block reassembly of lib/dtl/tb_decoder.cc:143-195 expressed as a gather table).
+struct CwDesc {
+    uint32_t llr_off0;  // first on-air soft bit (offset into the LLR stream)
+    uint32_t llr_off1;  // continuation when the codeword straddles two frames
+    uint32_t out_off;   // first decoded bit (1 bit per byte) in the output buffer
+    uint16_t len0;      // soft bits taken from llr_off0 (rest from llr_off1)
+    uint16_t k_used;    // systematic bits actually sent (k minus shortening)
+};
+
+struct LdpcTables {
+    int n, m, k, rank, n_edges, n_chk_pass, n_var_pass;
+    const ChkSlot* chk;
+    const VarSlot* var;
+    const uint16_t* col_edge;
+    const uint16_t* row_ptr;
+    const uint16_t* edge_var;
+    const uint16_t* inv_perm;  // y[v] = -llr[inv_perm[v]]           (ldpc_dec.cc:64-66)
+    const uint16_t* sys_src;   // data[i] = estimate[sys_src[i]]     (cldpc::get_systematic_bits)
+};
+
+class LdpcDecoder {
+public:
+    LdpcCode code;
+    int max_iterations = 15;  // lib/dtl/ldpc_dec.cc:27
+    float sigma = 1.41421356237f; // awgn_bp sigma: never set by gr-dtl; sqrt(2) => rx_lr = exp(llr)
+
+    ~LdpcDecoder();
+    int upload();  // build device tables
+    // llr: device float stream; desc==nullptr => codeword i at llr + i*n, all k bits, out at i*k
+    int decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, uint8_t* d_bits, int32_t* d_nit,
+               hipStream_t stream) const;
+    size_t lds_bytes() const;
+    bool uploaded() const { return blob_ != nullptr; }
+
+private:
+    LdpcTables t_{};
+    void* blob_ = nullptr;
+};
+
+} // namespace dtl

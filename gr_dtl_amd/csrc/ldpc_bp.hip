@@ -1,0 +1,214 @@
+// ldpc_bp.hip -- K10: LDPC sum-product belief propagation, one 64-lane wavefront per codeword.
+//
+// Replaces gr::dtl::ldpc_dec::decode (lib/dtl/ldpc_dec.cc:62-71) and the GNU Radio awgn_bp
+// decoder it drives.  Arithmetic is the reference's: likelihood-ratio domain, IEEE double,
+// same operand order per check row (mlist order) and per variable column (nlist order), so the
+// hard decisions and iteration counts equal the CPU decoder's.  No MFMA: there is no dense
+// contraction here, only 4 double divisions per Tanner-graph edge per iteration.
+//
+// Mapping to CDNA4:
+//  * one wavefront == one codeword; all messages of the codeword live in LDS (E doubles,
+//    7.1 KB for the (300,152) code) and are updated in place;
+//  * work is EDGE-parallel (lane == edge) so the 64 lanes stay ~93-99 % busy for any row/column
+//    weight; whole rows (check phase) / whole variables (variable phase) are packed into one
+//    64-lane pass so that an in-place update can never race with a sibling lane's read;
+//  * the syndrome is a per-check XOR of LDS bytes reduced with a 64-bit ballot;
+//  * a persistent grid strides over the codeword batch (codewords have 0..max_it iterations,
+//    the stride averages the imbalance); 16 single-wave workgroups fit a CU's 160 KB LDS.
+#include "ldpc_bp.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace dtl {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr float kShortenedValue = -15.0f; // lib/dtl/tb_decoder.cc:145
+
+__device__ __forceinline__ bool syndrome_is_zero(const LdpcTables& t, const uint8_t* est, int lane)
+{
+    unsigned bad = 0;
+    for (int c = lane; c < t.m; c += kWave) {
+        unsigned s = 0;
+        const int e1 = t.row_ptr[c + 1];
+        for (int e = t.row_ptr[c]; e < e1; e++) s ^= est[t.edge_var[e]];
+        bad |= s;
+    }
+    return __ballot(bad != 0) == 0ull;
+}
+
+__global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const float* __restrict__ llr,
+                                                       const CwDesc* __restrict__ desc, int ncw,
+                                                       int max_it, float sigma,
+                                                       uint8_t* __restrict__ out_bits,
+                                                       int32_t* __restrict__ out_nit)
+{
+    extern __shared__ double smem[];
+    double* msg = smem;                                  // n_edges doubles: Q / t / R in place
+    double* rx = msg + t.n_edges;                        // n doubles: channel likelihood ratios
+    uint8_t* est = reinterpret_cast<uint8_t*>(rx + t.n); // n bytes: hard decisions
+    float* ybuf = reinterpret_cast<float*>(msg);         // n floats, only before msg is live
+
+    const int lane = threadIdx.x;
+    const int ncheck = t.n - t.k;
+
+    for (int cw = blockIdx.x; cw < ncw; cw += gridDim.x) {
+        uint32_t off0, off1, out_off;
+        int len0, k_used;
+        if (desc) {
+            CwDesc d = desc[cw];
+            off0 = d.llr_off0; off1 = d.llr_off1; out_off = d.out_off; len0 = d.len0; k_used = d.k_used;
+        } else {
+            off0 = uint32_t(cw) * uint32_t(t.n); off1 = 0; out_off = uint32_t(cw) * uint32_t(t.k);
+            len0 = t.n; k_used = t.k;
+        }
+        const int n_sent = ncheck + k_used;
+
+        // y[permute[i]] = -llr[i]; shortened positions were never sent: -15 (tb_decoder.cc:163-183)
+        for (int v = lane; v < t.n; v += kWave) {
+            const int src = t.inv_perm[v];
+            float val = kShortenedValue;
+            if (src < n_sent) val = (src < len0) ? llr[size_t(off0) + src] : llr[size_t(off1) + (src - len0)];
+            const float y = -1 * val;
+            ybuf[v] = y;
+            est[v] = (y < 0) ? 1 : 0; // awgn_bp::compute_init_estimate
+        }
+        __syncthreads();
+
+        int nit = 0;
+        if (!syndrome_is_zero(t, est, lane)) {
+            // awgn_bp::rx_lr_calc
+            // (float expression, exp of the float-rounded argument; rx does not overlap ybuf)
+            const float s2 = sigma * sigma;
+            for (int v = lane; v < t.n; v += kWave) rx[v] = exp(double((-1 * 2 * ybuf[v]) / s2));
+            __syncthreads(); // ybuf (aliasing msg) is dead from here
+            // awgn_bp::spa_initialize
+            for (int e = lane; e < t.n_edges; e += kWave) msg[e] = rx[t.edge_var[e]];
+            __syncthreads();
+
+            while (nit < max_it) {
+                nit += 1;
+                // ---- awgn_bp::update_chks, part a: t_e = 2/(1+Q_e) - 1 for every edge
+#pragma unroll 2
+                for (int e = lane; e < t.n_edges; e += kWave) {
+                    const double q = msg[e];
+                    msg[e] = 2 / (1 + q) - 1;
+                }
+                __syncthreads();
+                // ---- part b: row product in mlist order, extrinsic ratio, R_e
+                for (int p = 0; p < t.n_chk_pass; p++) {
+                    const ChkSlot s = t.chk[p * kWave + lane];
+                    double r_new = 0.0;
+                    if (s.edge != 0xFFFF) {
+                        double product = 1.0;
+                        for (int j = 0; j < s.deg; j++) product = product * msg[s.row_start + j];
+                        const double prd = product / msg[s.edge];
+                        r_new = (1 - prd) / (1 + prd);
+                    }
+                    __syncthreads(); // every lane of the row has read before anyone writes
+                    if (s.edge != 0xFFFF) msg[s.edge] = r_new;
+                }
+                __syncthreads();
+                // ---- awgn_bp::update_vars + decision
+                for (int p = 0; p < t.n_var_pass; p++) {
+                    const VarSlot s = t.var[p * kWave + lane];
+                    double q_new = 0.0;
+                    if (s.edge != 0xFFFF) {
+                        double sum = rx[s.var];
+                        for (int i = 0; i < s.deg; i++) sum = sum * msg[t.col_edge[s.col_start + i]];
+                        q_new = sum / msg[s.edge];
+                        if (s.first) est[s.var] = (sum > 1) ? 1 : 0;
+                    }
+                    __syncthreads();
+                    if (s.edge != 0xFFFF) msg[s.edge] = q_new;
+                }
+                __syncthreads();
+                if (syndrome_is_zero(t, est, lane)) break;
+            }
+        }
+
+        // cldpc::get_systematic_bits; only the k_used bits that were sent are kept
+        for (int i = lane; i < k_used; i += kWave) out_bits[size_t(out_off) + i] = est[t.sys_src[i]];
+        if (lane == 0) out_nit[cw] = nit;
+        __syncthreads(); // LDS is reused by the next codeword
+    }
+}
+
+} // namespace
+
+LdpcDecoder::~LdpcDecoder()
+{
+    if (blob_) (void)hipFree(blob_);
+}
+
+size_t LdpcDecoder::lds_bytes() const
+{
+    return size_t(code.n_edges) * 8 + size_t(code.n) * 8 + size_t((code.n + 7) / 8) * 8;
+}
+
+int LdpcDecoder::upload()
+{
+    if (code.n <= 0 || code.n_edges <= 0) { set_last_error("ldpc: empty code"); return DTL_ERR_INVALID_ARG; }
+    if (size_t(code.n) * 4 > size_t(code.n_edges) * 8) { set_last_error("ldpc: n too large vs edges"); return DTL_ERR_UNSUPPORTED; }
+    // one allocation, 16-byte aligned sections
+    std::vector<uint8_t> host;
+    auto put = [&](const void* p, size_t bytes) {
+        size_t off = (host.size() + 15) & ~size_t(15);
+        host.resize(off + bytes);
+        std::memcpy(host.data() + off, p, bytes);
+        return off;
+    };
+    auto to16 = [](const std::vector<int>& v) { return std::vector<uint16_t>(v.begin(), v.end()); };
+    std::vector<uint16_t> col_edge = to16(code.col_edge), row_ptr = to16(code.row_ptr),
+                          edge_var = to16(code.edge_var), inv_perm(code.n), sys_src(code.k);
+    for (int i = 0; i < code.n; i++) inv_perm[code.permute[i]] = uint16_t(i);
+    for (int i = 0; i < code.k; i++) sys_src[i] = uint16_t(code.permute[i + code.rank]);
+    size_t o_chk = put(code.chk_sched.data(), code.chk_sched.size() * sizeof(ChkSlot));
+    size_t o_var = put(code.var_sched.data(), code.var_sched.size() * sizeof(VarSlot));
+    size_t o_ce = put(col_edge.data(), col_edge.size() * 2);
+    size_t o_rp = put(row_ptr.data(), row_ptr.size() * 2);
+    size_t o_ev = put(edge_var.data(), edge_var.size() * 2);
+    size_t o_ip = put(inv_perm.data(), inv_perm.size() * 2);
+    size_t o_ss = put(sys_src.data(), sys_src.size() * 2);
+    if (blob_) { (void)hipFree(blob_); blob_ = nullptr; }
+    DTL_HIP_CHECK(hipMalloc(&blob_, host.size()));
+    DTL_HIP_CHECK(hipMemcpy(blob_, host.data(), host.size(), hipMemcpyHostToDevice));
+    auto* b = static_cast<uint8_t*>(blob_);
+    t_.n = code.n; t_.m = code.m; t_.k = code.k; t_.rank = code.rank; t_.n_edges = code.n_edges;
+    t_.n_chk_pass = code.n_chk_pass; t_.n_var_pass = code.n_var_pass;
+    t_.chk = reinterpret_cast<const ChkSlot*>(b + o_chk);
+    t_.var = reinterpret_cast<const VarSlot*>(b + o_var);
+    t_.col_edge = reinterpret_cast<const uint16_t*>(b + o_ce);
+    t_.row_ptr = reinterpret_cast<const uint16_t*>(b + o_rp);
+    t_.edge_var = reinterpret_cast<const uint16_t*>(b + o_ev);
+    t_.inv_perm = reinterpret_cast<const uint16_t*>(b + o_ip);
+    t_.sys_src = reinterpret_cast<const uint16_t*>(b + o_ss);
+    return DTL_OK;
+}
+
+int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, uint8_t* d_bits,
+                        int32_t* d_nit, hipStream_t stream) const
+{
+    if (!blob_) { set_last_error("ldpc: tables not uploaded"); return DTL_ERR_INVALID_ARG; }
+    if (ncw == 0) return DTL_OK;
+    if (ncw > size_t(0x7fffffff)) { set_last_error("ldpc: batch too large"); return DTL_ERR_INVALID_ARG; }
+    if (!d_llr || !d_bits || !d_nit) { set_last_error("ldpc: null buffer"); return DTL_ERR_INVALID_ARG; }
+    if (!d_desc && ncw * size_t(code.n) > size_t(0xffffffffu)) {
+        set_last_error("ldpc: dense batch exceeds 32-bit soft-bit offsets");
+        return DTL_ERR_INVALID_ARG;
+    }
+    const size_t lds = lds_bytes();
+    const int waves_per_cu = int(std::min<size_t>(16, (160 * 1024) / lds));
+    int grid = int(std::min<size_t>(ncw, size_t(256) * waves_per_cu));
+    hipLaunchKernelGGL(ldpc_bp_kernel, dim3(grid), dim3(kWave), lds, stream, t_, d_llr, d_desc, int(ncw),
+                       max_iterations, sigma, d_bits, d_nit);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+} // namespace dtl
