@@ -1,0 +1,422 @@
+/*
+ * orc_ofdm.c -- ORACLE (test infrastructure, not product): the OFDM blocks of the receive graph
+ * (python/dtl/ofdm_receiver.py:59-246) and the OFDM half of the transmit graph
+ * (python/dtl/ofdm_transmitter.py:168-189, test-vector generator).
+ *
+ * gr-dtl code followed: lib/dtl/ofdm_adaptive_equalizer.cc, ofdm_adaptive_frame_equalizer_vcvc_impl.cc,
+ * ofdm_adaptive_frame_detect_bb_impl.cc, include/gnuradio/dtl/ofdm_adaptive_frame_snr.h.
+ * Stock GNU Radio 3.10 blocks (sources not in the reference tree; unverified restatement, see
+ * SURVEY.md 8c): ofdm_sync_sc_cfb, plateau_detector_fb, sample_and_hold_ff, delay,
+ * frequency_modulator_fc, fft_vcc, ofdm_chanest_vcvc, ofdm_frame_equalizer_vcvc,
+ * ofdm_equalizer_1d_pilots, mpsk_snr_est_simple, ofdm_serializer_vcc,
+ * ofdm_carrier_allocator_cvc, ofdm_cyclic_prefixer.
+ */
+#include "oracle.h"
+
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef float complex cf;
+
+static inline cf to_cf(orc_c32 v) { return v.re + v.im * I; }
+static inline orc_c32 from_cf(cf v) { return (orc_c32){ crealf(v), cimagf(v) }; }
+
+/* carrier index (may be negative) -> position in a shifted FFT vector (DC at N/2) */
+static inline int shifted_index(int carrier, int N)
+{
+    int idx = carrier < 0 ? carrier + N : carrier;
+    return (idx + N / 2) % N;
+}
+
+/* python/dtl/ofdm_adaptive.py:1-6 */
+int orc_frame_capacity(const orc_cfg* cfg)
+{
+    int n = 0;
+    for (int i = 0; i < cfg->frame_length; i++) n += cfg->occ_len[i % cfg->n_occ_sets];
+    return n;
+}
+
+/* ------------------------------------------------------------------ FFT */
+
+static void fft_inplace(cf* x, int n, int sign)
+{
+    /* iterative radix-2, twiddles evaluated in double */
+    for (int i = 1, j = 0; i < n; i++) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { cf t = x[i]; x[i] = x[j]; x[j] = t; }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        for (int i = 0; i < n; i += len) {
+            for (int k = 0; k < len / 2; k++) {
+                double ang = sign * 2.0 * M_PI * k / len;
+                cf w = (float)cos(ang) + (float)sin(ang) * I;
+                cf u = x[i + k];
+                cf a = x[i + k + len / 2];
+                cf v = (crealf(a) * crealf(w) - cimagf(a) * cimagf(w)) +
+                       (crealf(a) * cimagf(w) + cimagf(a) * crealf(w)) * I;
+                x[i + k] = u + v;
+                x[i + k + len / 2] = u - v;
+            }
+        }
+    }
+}
+
+/* GR3.10 fft_vcc: forward = execute then swap halves; inverse = swap halves then execute;
+ * FFTW convention: unnormalised, forward exponent -j. */
+void orc_fft_shifted(const orc_c32* in, orc_c32* out, int n, int forward)
+{
+    cf* tmp = (cf*)malloc(n * sizeof(cf));
+    if (forward) {
+        for (int i = 0; i < n; i++) tmp[i] = to_cf(in[i]);
+        fft_inplace(tmp, n, -1);
+        for (int k = 0; k < n; k++) out[(k + n / 2) % n] = from_cf(tmp[k]);
+    } else {
+        for (int k = 0; k < n; k++) tmp[k] = to_cf(in[(k + n / 2) % n]);
+        fft_inplace(tmp, n, +1);
+        for (int i = 0; i < n; i++) out[i] = from_cf(tmp[i]);
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ TX */
+
+void orc_tx_frame(const orc_cfg* cfg, const uint8_t* hdr_bits, const uint8_t* payload_syms,
+                  int cnst, orc_c32* out)
+{
+    const int N = cfg->fft_len, cp = cfg->cp_len;
+    const int n_data_syms = cfg->header_len + cfg->frame_length;
+    orc_c32* freq = (orc_c32*)calloc((size_t)N, sizeof(orc_c32));
+    orc_c32* time = (orc_c32*)calloc((size_t)N, sizeof(orc_c32));
+    orc_c32 bpsk[16], pts[16];
+    orc_constellation_points(ORC_CNST_BPSK, bpsk);
+    orc_constellation_points(cnst, pts);
+    int hdr_pos = 0, pay_pos = 0;
+    for (int s = 0; s < 2 + n_data_syms; s++) {
+        memset(freq, 0, N * sizeof(orc_c32));
+        if (s == 0) memcpy(freq, cfg->sync1, N * sizeof(orc_c32));
+        else if (s == 1) memcpy(freq, cfg->sync2, N * sizeof(orc_c32));
+        else {
+            /* ofdm_carrier_allocator_cvc: symbol i of the tagged frame (header first) */
+            int i = s - 2;
+            int set = i % cfg->n_occ_sets;
+            for (int k = 0; k < cfg->occ_len[set]; k++) {
+                int idx = shifted_index(cfg->occ[set * cfg->max_occ + k], N);
+                if (i < cfg->header_len) freq[idx] = bpsk[hdr_bits[hdr_pos++] & 1]; /* chunks_to_symbols_bc(bpsk) */
+                else freq[idx] = pts[payload_syms[pay_pos++]];                      /* map_to_points */
+            }
+            int pset = i % cfg->n_pilot_sets;
+            for (int k = 0; k < cfg->n_pilots; k++)
+                freq[shifted_index(cfg->pilot_carriers[pset * cfg->n_pilots + k], N)] =
+                    cfg->pilot_symbols[(i % cfg->n_pilot_sym_sets) * cfg->n_pilots + k];
+        }
+        orc_fft_shifted(freq, time, N, 0);
+        /* ofdm_cyclic_prefixer, rolloff 0 */
+        orc_c32* o = &out[(size_t)s * (N + cp)];
+        memcpy(o, &time[N - cp], cp * sizeof(orc_c32));
+        memcpy(o + cp, time, N * sizeof(orc_c32));
+    }
+    free(freq); free(time);
+}
+
+/* ------------------------------------------------------------------ Schmidl & Cox */
+
+void orc_sync_sc(const orc_cfg* cfg, const orc_c32* iq, long n, float* metric_out, uint8_t* trig,
+                 float* angle)
+{
+    const int N = cfg->fft_len, half = N / 2, max_len = cfg->cp_len;
+    const float thr = cfg->sync_threshold;
+    float* metric = metric_out ? metric_out : (float*)malloc(n * sizeof(float));
+    float* arg = (float*)malloc(n * sizeof(float));
+    /* delay(N/2) -> conjugate -> multiply_cc -> fir_filter_ccf(N/2 taps of -1)   [P]
+     * complex_to_mag_squared -> fir_filter_fff(N taps of 0.5) -> multiply_ff(x,x) [E^2]
+     * metric = |P|^2 / E^2 ; angle = arg(P).  Window sums are accumulated in double and
+     * rounded to float once (the reference's float FIR order is SIMD-dependent). */
+    double pr = 0, pi = 0, en = 0;
+    for (long i = 0; i < n; i++) {
+        cf cur = to_cf(iq[i]);
+        cf dly = (i >= half) ? to_cf(iq[i - half]) : 0;
+        cf c = cur * conjf(dly);
+        pr += crealf(c); pi += cimagf(c);
+        if (i >= half) {
+            cf co = to_cf(iq[i - half]);
+            cf dlo = (i - half >= half) ? to_cf(iq[i - 2 * half]) : 0;
+            cf cold = co * conjf(dlo);
+            pr -= crealf(cold); pi -= cimagf(cold);
+        }
+        float e = crealf(cur) * crealf(cur) + cimagf(cur) * cimagf(cur);
+        en += 0.5f * e;
+        if (i >= N) {
+            cf o = to_cf(iq[i - N]);
+            en -= 0.5f * (crealf(o) * crealf(o) + cimagf(o) * cimagf(o));
+        }
+        float Pr = (float)(-pr), Pi = (float)(-pi), E = (float)en;
+        float num = Pr * Pr + Pi * Pi;
+        metric[i] = num / (E * E);
+        arg[i] = atan2f(Pi, Pr);
+    }
+    /* plateau_detector_fb(max_len = cp_len, threshold), unbounded-buffer form */
+    memset(trig, 0, n);
+    for (long i = 0; i < n; i++) {
+        if (metric[i] >= thr) {
+            long flank_start = i;
+            while (i < n && metric[i] >= thr) i++;
+            if ((i - flank_start) > 1) {
+                trig[flank_start + (i - flank_start) / 2] = 1;
+                i = (i + max_len < n - 1) ? i + max_len : n - 1;
+            }
+        }
+    }
+    /* sample_and_hold_ff */
+    float held = 0;
+    for (long i = 0; i < n; i++) {
+        if (trig[i]) held = arg[i];
+        angle[i] = held;
+    }
+    if (!metric_out) free(metric);
+    free(arg);
+}
+
+void orc_framedetect_init(orc_framedetect* s, int frame_len)
+{
+    memset(s, 0, sizeof(*s));
+    s->frame_len = frame_len;
+}
+
+/* lib/dtl/ofdm_adaptive_frame_detect_bb_impl.cc:64-173 (constants :21-22) */
+void orc_fix_sync(orc_framedetect* s, const uint8_t* in, uint8_t* out, int len)
+{
+    const int CONSECUTIVE_SYNCED_FRAMES_TH = 3, MAX_CONSECUTIVE_MISSING_CORRECTION = 5;
+    int last_trigger_index = -s->remainder;
+    int trigger_found = 0;
+    memcpy(out, in, len);
+    for (int i = 0, index = s->remainder; i < len; ++i, ++index) {
+        if (out[i]) {
+            int frame_len_detected = i - last_trigger_index;
+            int diff = frame_len_detected - s->frame_len;
+            index = 0;
+            if (s->acc_error) ++s->trigger_counter;
+            int inst_error = abs(diff);
+            if (inst_error == 1) s->acc_error += diff;
+            s->error_count += (inst_error != 0);
+            if (inst_error == 0 || inst_error == 1) {
+                if (s->synced < CONSECUTIVE_SYNCED_FRAMES_TH) ++s->synced;
+                else s->in_sync = 1;
+            } else {
+                s->synced = 0;
+                s->in_sync = 0;
+            }
+            if (s->acc_error > 1 || (inst_error > 1 && inst_error < 10)) {
+                if (last_trigger_index + s->frame_len < len) {
+                    out[i] = 0;
+                    last_trigger_index += s->frame_len;
+                    out[last_trigger_index] = 1;
+                    i = last_trigger_index;
+                    s->acc_error = 0;
+                    ++s->correction_count;
+                } else {
+                    last_trigger_index = i;
+                }
+            } else {
+                last_trigger_index = i;
+            }
+            s->remainder = len - last_trigger_index;
+            trigger_found = 1;
+            if (s->trigger_counter > 10) s->acc_error = 0;
+        } else if (s->in_sync && (index > s->frame_len + 10 ||
+                                  (index > s->frame_len + 1 && i == len - 1))) {
+            last_trigger_index += s->frame_len;
+            out[last_trigger_index] = 1;
+            i = last_trigger_index;
+            index = 0;
+            trigger_found = 1;
+            s->remainder = len - last_trigger_index;
+            ++s->missing_count;
+            if (--s->synced < CONSECUTIVE_SYNCED_FRAMES_TH - MAX_CONSECUTIVE_MISSING_CORRECTION) {
+                s->in_sync = 0;
+                s->synced = 0;
+            }
+        }
+    }
+    if (!trigger_found) s->remainder += len;
+}
+
+/* delay(N+cp) ; frequency_modulator_fc(-2.0/N) ; multiply_cc.  The oscillator phase is kept in
+ * double and wrapped to [-pi, pi) (the reference keeps a float accumulator and a fixed-point
+ * sin/cos table: ~1e-4 of its own error). */
+void orc_cfo_mix(const orc_cfg* cfg, const orc_c32* iq, long n, const float* angle, orc_c32* out)
+{
+    const int dly = cfg->fft_len + cfg->cp_len;
+    const float sens = (float)(-2.0 / cfg->fft_len);
+    double phase = 0;
+    for (long i = 0; i < n; i++) {
+        phase = phase + (double)(sens * angle[i]);
+        phase = fmod(phase + M_PI, 2.0 * M_PI);
+        if (phase < 0) phase += 2.0 * M_PI;
+        phase -= M_PI;
+        float ph = (float)phase;
+        cf osc = cosf(ph) + sinf(ph) * I;
+        cf smp = (i >= dly) ? to_cf(iq[i - dly]) : 0;
+        cf r = (crealf(smp) * crealf(osc) - cimagf(smp) * cimagf(osc)) +
+               (crealf(smp) * cimagf(osc) + cimagf(smp) * crealf(osc)) * I;
+        out[i] = from_cf(r);
+    }
+}
+
+/* ------------------------------------------------------------------ channel estimate */
+
+int orc_chanest(const orc_cfg* cfg, const orc_c32* sync_syms, orc_c32* taps)
+{
+    const int N = cfg->fft_len;
+    const orc_c32* s1 = cfg->sync1;
+    const orc_c32* ref = cfg->sync2; /* d_ref_sym = sync_symbol2 (two sync symbols) */
+    int first_active = 0, last_active = N - 1;
+    for (int i = 0; i < N; i++) if (ref[i].re != 0 || ref[i].im != 0) { first_active = i; break; }
+    for (int i = N - 1; i >= 0; i--) if (ref[i].re != 0 || ref[i].im != 0) { last_active = i; break; }
+    int max_neg = -first_active, max_pos = N - last_active - 1;
+    if (max_neg % 2) max_neg++;
+    if (max_pos % 2) max_pos--;
+    cf* corr_v = (cf*)calloc(N, sizeof(cf));
+    for (int i = 0; i < N; i++) {
+        if (s1[i].re == 0 && s1[i].im == 0) corr_v[i] = 0;
+        else corr_v[i] = to_cf(cfg->sync2[i]) / to_cf(s1[i]);
+    }
+    const orc_c32* y1 = sync_syms;
+    const orc_c32* y2 = sync_syms + N;
+    /* get_carr_offset: Schmidl & Cox coarse estimate, even offsets only */
+    int carr_offset = 0;
+    float Bg_max = 0;
+    for (int g = max_neg; g <= max_pos; g += 2) {
+        cf tmp = 0;
+        for (int k = 0; k < N; k++)
+            if (corr_v[k] != 0) tmp += conjf(to_cf(y1[k + g])) * conjf(corr_v[k]) * to_cf(y2[k + g]);
+        if (cabsf(tmp) > Bg_max) { Bg_max = cabsf(tmp); carr_offset = g; }
+    }
+    /* get_chan_taps */
+    for (int i = 0; i < N; i++) taps[i] = (orc_c32){ 0, 0 };
+    int loop_start = 0, loop_end = N;
+    if (carr_offset > 0) loop_start = carr_offset;
+    else if (carr_offset < 0) loop_end = N + carr_offset;
+    for (int i = loop_start; i < loop_end; i++)
+        if (ref[i - carr_offset].re != 0 || ref[i - carr_offset].im != 0)
+            taps[i - carr_offset] = from_cf(to_cf(y2[i]) / to_cf(ref[i - carr_offset]));
+    free(corr_v);
+    return carr_offset;
+}
+
+/* ------------------------------------------------------------------ frame equaliser */
+
+void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c32* in, int n_sym,
+                        int carrier_offset, orc_c32* taps_io, orc_c32* hard, orc_c32* soft,
+                        orc_snr* snr_out)
+{
+    const int N = cfg->fft_len, cp = cfg->cp_len;
+    const long total = (long)N * n_sym;
+    cf* out = (cf*)calloc(total, sizeof(cf));
+    /* integer-CFO shift with zero fill (frame_equalizer_vcvc_impl.cc:154-166) */
+    if (carrier_offset < 0) {
+        for (long i = 0; i < total + carrier_offset; i++) out[i - carrier_offset] = to_cf(in[i]);
+    } else {
+        for (long i = 0; i < total - carrier_offset; i++) out[i] = to_cf(in[i + carrier_offset]);
+    }
+    /* per-symbol phase derotation (:170-177) */
+    for (int i = 0; i < n_sym; i++) {
+        float ph = (float)(-(2.0 * M_PI) * carrier_offset * cp / N * (i + 1));
+        cf pc = cosf(ph) + sinf(ph) * I;
+        for (int k = 0; k < N; k++) out[(long)i * N + k] *= pc;
+    }
+    /* masks: ofdm_equalizer_1d_pilots ctor (input_is_shifted = true) + equalizer.cc:196-214 */
+    uint8_t* occupied = (uint8_t*)calloc(N, 1);
+    for (int s = 0; s < cfg->n_occ_sets; s++)
+        for (int k = 0; k < cfg->occ_len[s]; k++) occupied[shifted_index(cfg->occ[s * cfg->max_occ + k], N)] = 1;
+    uint8_t* pilot_mask = (uint8_t*)calloc((size_t)cfg->n_pilot_sets * N, 1);
+    for (int s = 0; s < cfg->n_pilot_sets; s++)
+        for (int k = 0; k < cfg->n_pilots; k++)
+            pilot_mask[s * N + shifted_index(cfg->pilot_carriers[s * cfg->n_pilots + k], N)] = 1;
+    cf* pilot_sym = (cf*)calloc((size_t)cfg->n_pilot_sym_sets * N, sizeof(cf));
+    for (int s = 0; s < cfg->n_pilot_sym_sets; s++) {
+        int cset = s % cfg->n_pilot_sets;
+        for (int k = 0; k < cfg->n_pilots; k++)
+            pilot_sym[s * N + shifted_index(cfg->pilot_carriers[cset * cfg->n_pilots + k], N)] =
+                to_cf(cfg->pilot_symbols[s * cfg->n_pilots + k]);
+    }
+    /* header: ctor passes (symbols_skipped, input_is_shifted, alpha) into (symbols_skipped, alpha,
+     * input_is_shifted) => alpha = 1.0 (equalizer.cc:147-154); the Python call gives
+     * symbols_skipped = 0 for the header, header_len for the payload (ofdm_receiver.py:111,162) */
+    const float alpha = is_header ? 1.0f : cfg->eq_alpha;
+    const int symbols_skipped = is_header ? 0 : cfg->header_len;
+    orc_c32 pts[16];
+    orc_constellation_points(cnst, pts);
+    /* d_eq->reset(): channel state <- 1, pilot carrier set <- skipped % sets; then initial taps */
+    cf* H = (cf*)malloc(N * sizeof(cf));
+    for (int k = 0; k < N; k++) H[k] = to_cf(taps_io[k]);
+    int pilot_carr_set = cfg->n_pilot_sets ? symbols_skipped % cfg->n_pilot_sets : 0;
+    /* mpsk_snr_est_simple(alpha) fresh each frame (ofdm_adaptive_frame_snr.h:35) */
+    double y1 = 0, y2 = 0, counter = 1;
+    for (int i = 0; i < n_sym; i++) {
+        int pset = (symbols_skipped + i) % cfg->n_pilot_sym_sets;
+        for (int k = 0; k < N; k++) {
+            int is_pilot = cfg->n_pilot_sets && pilot_mask[pilot_carr_set * N + k];
+            if (!occupied[k] && !is_pilot) continue;
+            long p = (long)i * N + k;
+            if (is_pilot) {
+                cf pilot_eq = out[p] / H[k];
+                /* mpsk_snr_est_simple::update: Welford mean/variance of |x| (double) */
+                double x = cabsf(pilot_eq);
+                double y1_prime = y1 + (x - y1) / counter;
+                y2 += (x - y1) * (x - y1_prime);
+                y1 = y1_prime;
+                counter++;
+                H[k] = alpha * H[k] + (1 - alpha) * out[p] / pilot_sym[pset * N + k];
+                out[p] = pilot_sym[pset * N + k];
+            } else {
+                cf sym_eq = out[p] / H[k];
+                cf sym_est = to_cf(pts[orc_decision_maker(cnst, from_cf(sym_eq))]);
+                H[k] = alpha * H[k] + (1 - alpha) * out[p] / sym_est;
+                out[p] = sym_est;
+                if (soft) soft[p] = from_cf(sym_eq);
+            }
+        }
+        if (cfg->n_pilot_sets) pilot_carr_set = (pilot_carr_set + 1) % cfg->n_pilot_sets;
+    }
+    if (soft) /* carriers the equaliser skips are left untouched by the reference: define as 0 */
+        for (int i = 0; i < n_sym; i++)
+            for (int k = 0; k < N; k++) {
+                int pcs = cfg->n_pilot_sets ? (symbols_skipped + i) % cfg->n_pilot_sets : 0;
+                int is_pilot = cfg->n_pilot_sets && pilot_mask[pcs * N + k];
+                if (is_pilot || !occupied[k]) soft[(long)i * N + k] = (orc_c32){ 0, 0 };
+            }
+    for (long i = 0; i < total; i++) hard[i] = from_cf(out[i]);
+    /* mpsk_snr_est_simple::snr()/noise() and get_noise() (equalizer.cc:279-287) */
+    if (snr_out) {
+        double signal_db = 10.0 * log10(fabs(y1 * y1));
+        double noise_db = 10.0 * log10(2.0 * y2 / (counter - 1));
+        snr_out->snr_db = signal_db - noise_db;
+        snr_out->noise_db = noise_db;
+        snr_out->noise_lin = pow(10, noise_db / 10.0);
+    }
+    /* channel state out, rotated by the frame's accumulated phase (:189-193) */
+    float ph = (float)((2.0 * M_PI) * carrier_offset * cp / N * n_sym);
+    cf pc = cosf(ph) + sinf(ph) * I;
+    for (int k = 0; k < N; k++) taps_io[k] = from_cf(H[k] * pc);
+    free(out); free(occupied); free(pilot_mask); free(pilot_sym); free(H);
+}
+
+/* GR3.10 ofdm_serializer_vcc, input_is_shifted = true, no carrier-offset key */
+int orc_serialize(const orc_cfg* cfg, const orc_c32* frame, int n_sym, int symbols_skipped,
+                  int packet_len, orc_c32* out)
+{
+    const int N = cfg->fft_len;
+    int curr_set = symbols_skipped % cfg->n_occ_sets;
+    int n_out = 0;
+    for (int i = 0; i < n_sym; i++) {
+        for (int k = 0; k < cfg->occ_len[curr_set]; k++)
+            out[n_out++] = frame[(long)i * N + shifted_index(cfg->occ[curr_set * cfg->max_occ + k], N)];
+        if (packet_len && n_out > packet_len) { n_out = packet_len; break; }
+        curr_set = (curr_set + 1) % cfg->n_occ_sets;
+    }
+    return n_out;
+}

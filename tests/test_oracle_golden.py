@@ -1,0 +1,169 @@
+"""Pins the CPU oracle against every known answer the reference's own tests hold for the RX path
+(SURVEY.md 8c): tests/golden/reference_known_answers.json."""
+import json
+import os
+
+import numpy as np
+
+from conftest import CODES, GOLDEN
+
+G = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))
+
+
+def test_header_no_fec_format_and_parse(oracle):
+    g = G["packet_header_no_fec"]
+    state = oracle.QAM16
+    for i, bits in enumerate(g["bits"]):
+        fields = dict(payload_len=g["packets_len"][i], frame_no=i, cnst=g["constellations"][i], fb_cnst=0)
+        out = oracle.header_format(fields, False, 48)
+        assert out.tolist() == bits
+        ok, h, n_syms, state = oracle.header_parse(bits, False, state)
+        assert ok and h["payload_len"] == g["packets_len"][i] and h["frame_no"] == i
+        assert h["cnst"] == g["constellations"][i] and h["fb_cnst"] == 0
+        assert n_syms == g["parsed_len_syms"][i]
+        crc = sum(b << j for j, b in enumerate(bits[32:48]))
+        assert crc == G["crc16_values_no_fec"]["values"][i]
+
+
+def test_header_fec_format_and_parse(oracle):
+    g = G["packet_header_fec"]
+    state = oracle.QAM16
+    for i, bits in enumerate(g["bits"]):
+        f = g["fec"][i]
+        fields = dict(payload_len=g["packets_len"][i], frame_no=i, cnst=g["constellations"][i], fb_cnst=0,
+                      tb_no=f[0], tb_offset=f[1], fec=f[2], tb_payload=f[3], fec_fb=0)
+        out = oracle.header_format(fields, True, 96)
+        assert out.tolist() == bits
+        ok, h, n_syms, state = oracle.header_parse(bits, True, state)
+        assert ok
+        for k, v in fields.items():
+            assert h[k] == v, k
+        assert n_syms == g["parsed_len_syms"][i]
+        bad = list(bits)
+        bad[40] ^= 1
+        assert not oracle.header_parse(bad, True, state)[0]
+
+
+def test_frame_pack_lsb_first(oracle):
+    g = G["frame_pack_lsb_first"]
+    got = []
+    for p in g["packets"]:
+        bps = oracle.bits_per_symbol(p["cnst"])
+        by = oracle.repack_lsb_first(p["symbols"], bps, 8)
+        n = by.size - (1 if len(p["symbols"]) * bps % 8 else 0)   # frame_pack_bb_impl.cc:85-87
+        got += by[:n - 4].tolist()                                 # CRC bytes stripped (:123)
+    assert got == g["expected_bytes"]
+
+
+def test_constellation_metric_constant(oracle):
+    p8, pb = oracle.constellation_points(oracle.PSK8), oracle.constellation_points(oracle.BPSK)
+    dmin2 = min(abs(p8[i] - p8[j]) ** 2 for i in range(8) for j in range(i))
+    val = abs(p8[0] - pb[0]) ** 2 / dmin2
+    assert abs(val - G["constellation_metric"]["value"]) < 1e-5
+    assert abs(p8[0] - np.exp(1j * np.pi / 8)) < 1e-6 and pb[0] == -1
+
+
+def test_qpsk_map_slice_identity_all_constellations(oracle):
+    syms = G["qpsk_map_slice_identity"]["symbols"]
+    pts = oracle.constellation_points(oracle.QPSK)
+    assert oracle.decision_maker(oracle.QPSK, pts[syms]).tolist() == syms
+    for c in (oracle.BPSK, oracle.PSK8, oracle.QAM16):
+        pts = oracle.constellation_points(c)
+        assert oracle.decision_maker(c, pts).tolist() == list(range(len(pts)))
+
+
+def test_feedback_decision_sequence(oracle):
+    g = G["feedback_decision"]
+    fd = oracle.FeedbackDecision(g["hysteresis"], g["decision_th"], [(m[0], tuple(m[1])) for m in g["mcs"]],
+                                 g["initial_mcs"])
+    got = [fd.get_feedback(s)[0] for s in g["snr_inputs"]]
+    assert got == g["expected_cnst"]
+
+
+def test_crc32_check_value(oracle):
+    g = G["crc32_check"]
+    data = np.frombuffer(g["input_ascii"].encode(), np.uint8)
+    assert oracle.crc_compute(32, 0x04C11DB7, 0xFFFFFFFF, 0xFFFFFFFF, True, True, data) == g["value"]
+    buf = oracle.crc32_append(data)
+    assert oracle.crc32_verify(buf) and buf[-4:].tolist() == [0x26, 0x39, 0xF4, 0xCB]
+    buf[0] ^= 1
+    assert not oracle.crc32_verify(buf)
+
+
+def test_ldpc_dimensions_and_encode_decode_identity(oracle):
+    rng = np.random.default_rng(0)
+    for name, n, k in G["ldpc_dimensions"]["codes"]:
+        c = oracle.Ldpc(os.path.join(CODES, name))
+        assert (c.n, c.k) == (n, k)
+        assert sorted(c.permute.tolist()) == list(range(n))
+        for _ in range(5):
+            d = rng.integers(0, 2, k).astype(np.uint8)
+            cw = c.encode(d)
+            out, nit = c.decode((2.0 * cw - 1) * 7)
+            assert nit == 0 and (out == d).all()
+
+
+def test_fec_chain_round_trip_noise_free(oracle):
+    """qa_ofdm_adaptive_fec.py:71-141 style: fec_frame -> symbols -> soft demap (no noise tag) ->
+    fec decoder, 4 MCS x 2 codes x frame_len {3,10} x 48 carriers; output == input."""
+    rng = np.random.default_rng(7)
+    for code_name in ("n_0100_k_0023_gap_10.alist", "n_0100_k_0027_gap_04.alist"):
+        code = oracle.Ldpc(os.path.join(CODES, code_name))
+        for cnst in (1, 2, 3, 4):
+            for frame_len in (3, 10):
+                cap = frame_len * 48
+                user = rng.integers(0, 256, 200).astype(np.uint8)
+                syms, hdrs = oracle.fec_frames_build(code, 1, cnst, cap, user)
+                dec = oracle.TbDecoder(code, cap)
+                pts = oracle.constellation_points(cnst)
+                bits = []
+                for s, h in zip(syms, hdrs):
+                    bps = oracle.bits_per_symbol(cnst)
+                    n_syms = -(-h["payload_len"] * 8 // bps)
+                    llr = oracle.soft_demap(cnst, pts[s[:n_syms]], None)
+                    b, _ = dec.frame(llr, cnst, h)
+                    bits.append(b)
+                bits = np.concatenate(bits)
+                got = np.packbits(bits.reshape(-1, 8)[:, ::-1], axis=1).ravel()
+                assert np.array_equal(got, user), (code_name, cnst, frame_len)
+
+
+def _check_tbs(r, user, tb_bytes, numbering):
+    """Every CRC-ok TB / frame must carry exactly the bytes that were sent in it."""
+    good = 0
+    for t in r["tbs"]:
+        if not t["crc_ok"]:
+            continue
+        idx = t["tb_no"] - 1 if numbering == "tb" else t["tb_no"]
+        want = user[idx * tb_bytes:(idx + 1) * tb_bytes]
+        if numbering == "tb":
+            bits = r["user_bits"][t["out_offset"]:t["out_offset"] + t["user_bits"]]
+            got = np.packbits(bits.reshape(-1, 8)[:, ::-1], axis=1).ravel()
+        else:
+            got = r["user_bytes"][t["out_offset"]:t["out_offset"] + t["user_bits"] // 8]
+        assert np.array_equal(got[:want.size], want), t
+        good += 1
+    return good
+
+
+def test_txrx_round_trip_noise_free(oracle):
+    """qa_ofdm_adaptive_txrx.py:49-114,186-256 style: full TX -> (zeros padded) -> full RX; no-FEC 8PSK
+    (test_001) and FEC BPSK (test_003, code (100,23)), frame_length 10, sync_threshold 0.99.  Every
+    TB that passes its CRC is byte-exact; a frame whose Schmidl-Cox trigger lands one sample early is
+    lost by the demux (restated GR3.10 header_payload_demux semantics), hence ">= 95 %"."""
+    rng = np.random.default_rng(9)
+    user = rng.integers(0, 256, 4000).astype(np.uint8)
+    cfg = oracle.Config(frame_length=10, has_fec=False, sync_threshold=0.99)
+    syms, hdrs = oracle.nofec_frames_build(oracle.PSK8, cfg.frame_capacity, user)
+    x = oracle.awgn_stream(oracle.tx_frames(cfg, syms, hdrs), 0.0, 0)
+    r = oracle.rx_stream(cfg, None, x)
+    per = cfg.frame_capacity * 3 // 8 - 4
+    assert _check_tbs(r, user, per, "frame") >= 0.95 * len(hdrs)
+
+    cfg = oracle.Config(frame_length=10, has_fec=True, sync_threshold=0.99)
+    code = oracle.Ldpc(os.path.join(CODES, "n_0100_k_0023_gap_10.alist"))
+    syms, hdrs = oracle.fec_frames_build(code, 1, oracle.BPSK, cfg.frame_capacity, user[:1500])
+    x = oracle.awgn_stream(oracle.tx_frames(cfg, syms, hdrs), 0.0, 0)
+    r = oracle.rx_stream(cfg, code, x)
+    assert _check_tbs(r, user[:1500], 10, "tb") >= 0.95 * 150
+    assert all(t["avg_it"] == 0 for t in r["tbs"] if t["crc_ok"])
