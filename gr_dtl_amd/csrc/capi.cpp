@@ -3,7 +3,10 @@
 
 #include "dtl_common.h"
 #include "ldpc_bp.h"
+#include "rx_pipeline.h"
 
+#include <algorithm>
+#include <cstring>
 #include <fstream>
 #include <mutex>
 #include <new>
@@ -21,7 +24,13 @@ struct dtl_ldpc {
     dtl::LdpcDecoder dec;
 };
 
+struct dtl_rx {
+    dtl::Receiver rx;
+};
+
 static_assert(sizeof(dtl_cw_desc) == sizeof(dtl::CwDesc), "C ABI gather descriptor layout");
+static_assert(sizeof(dtl_rx_frame_info) == sizeof(dtl::FrameInfo), "C ABI frame info layout");
+static_assert(sizeof(dtl_rx_tb_info) == sizeof(dtl::TbInfo), "C ABI TB info layout");
 
 extern "C" {
 
@@ -109,6 +118,136 @@ int dtl_ldpc_decode_batch(const dtl_ldpc* h, const float* d_llr, size_t ncw, uin
                           int32_t* d_nit, void* stream)
 {
     return dtl_ldpc_decode_gather(h, d_llr, nullptr, ncw, d_bits, d_nit, stream);
+}
+
+
+int dtl_rx_create(const dtl_rx_cfg* c, dtl_rx** out)
+{
+    if (!c || !out) { dtl::set_last_error("rx_create: null argument"); return DTL_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (c->fft_len <= 0 || c->n_occ_sets <= 0 || !c->occ || !c->occ_len || !c->sync_word1 || !c->sync_word2) {
+        dtl::set_last_error("rx_create: incomplete configuration");
+        return DTL_ERR_INVALID_ARG;
+    }
+    auto* h = new (std::nothrow) dtl_rx();
+    if (!h) return DTL_ERR_CAPACITY;
+    dtl::RxConfig& g = h->rx.cfg;
+    g.fft_len = c->fft_len; g.cp_len = c->cp_len; g.frame_length = c->frame_length; g.has_fec = c->has_fec != 0;
+    for (int s = 0; s < c->n_occ_sets; s++)
+        g.occupied_carriers.emplace_back(c->occ + size_t(s) * c->max_occ, c->occ + size_t(s) * c->max_occ + c->occ_len[s]);
+    for (int s = 0; s < c->n_pilot_sets; s++)
+        g.pilot_carriers.emplace_back(c->pilot_carriers + size_t(s) * c->n_pilots, c->pilot_carriers + size_t(s + 1) * c->n_pilots);
+    for (int s = 0; s < c->n_pilot_sym_sets; s++) {
+        std::vector<dtl::cf32> row(c->n_pilots);
+        for (int k = 0; k < c->n_pilots; k++) row[k] = { c->pilot_symbols[2 * (size_t(s) * c->n_pilots + k)], c->pilot_symbols[2 * (size_t(s) * c->n_pilots + k) + 1] };
+        g.pilot_symbols.push_back(std::move(row));
+    }
+    g.sync_word1.resize(c->fft_len); g.sync_word2.resize(c->fft_len);
+    for (int i = 0; i < c->fft_len; i++) {
+        g.sync_word1[i] = { c->sync_word1[2 * i], c->sync_word1[2 * i + 1] };
+        g.sync_word2[i] = { c->sync_word2[2 * i], c->sync_word2[2 * i + 1] };
+    }
+    g.sync_threshold = c->sync_threshold; g.eq_alpha = c->eq_alpha;
+    g.use_sync_correct = c->use_sync_correct != 0; g.scramble_header = c->scramble_header != 0;
+    g.llr_dist_mode = c->llr_dist_mode; g.max_iterations = c->max_iterations; g.bp_sigma = c->bp_sigma;
+    for (int i = 0; i < c->n_fec_codes; i++) g.alist_texts.emplace_back(c->alist_texts[i], c->alist_lens[i]);
+    for (int i = 0; i < c->n_mcs; i++) g.mcs.push_back({ c->mcs_snr[i], c->mcs_cnst[i], c->mcs_fec[i] });
+    g.initial_mcs = c->initial_mcs; g.hysteresis = c->hysteresis; g.decision_th = c->decision_th > 0 ? c->decision_th : 5;
+    int rc = h->rx.init();
+    if (rc != DTL_OK) { delete h; return rc; }
+    *out = h;
+    return DTL_OK;
+}
+
+void dtl_rx_destroy(dtl_rx* h) { delete h; }
+
+int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void* stream, dtl_rx_result* out)
+{
+    if (!h || !out) { dtl::set_last_error("rx_process: null argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    dtl::Receiver& r = h->rx;
+    int rc = r.process(reinterpret_cast<const dtl::cf32*>(d_iq), n, flags, static_cast<hipStream_t>(stream));
+    if (rc != DTL_OK) return rc;
+    std::memset(out, 0, sizeof(*out));
+    out->n_frames = int64_t(r.frames.size());
+    out->n_payload_frames = r.n_payload_frames;
+    out->n_tbs = int64_t(r.tbs.size());
+    out->n_payload_bytes = r.n_payload_bytes;
+    out->n_raw_triggers = int64_t(r.raw_triggers.size());
+    out->n_fixed_triggers = int64_t(r.fixed_triggers.size());
+    out->n_llr = r.n_llr; out->n_codewords = r.n_codewords;
+    out->frames = reinterpret_cast<const dtl_rx_frame_info*>(r.frames.data());
+    out->tbs = reinterpret_cast<const dtl_rx_tb_info*>(r.tbs.data());
+    out->raw_triggers = r.raw_triggers.data();
+    out->fixed_triggers = r.fixed_triggers.data();
+    out->trigger_angles = r.trigger_angles.data();
+    out->d_payload = r.d_payload.as<uint8_t>();
+    out->d_eq_hard = (flags & DTL_RX_WANT_EQ_HARD) ? r.d_eq_hard.as<float>() : nullptr;
+    out->d_eq_soft = (flags & DTL_RX_WANT_EQ_SOFT) ? r.d_eq_soft.as<float>() : nullptr;
+    out->d_soft_syms = (flags & DTL_RX_WANT_SOFT_SYMS) ? r.d_soft_syms.as<float>() : nullptr;
+    out->d_llr = r.d_llr.as<float>();
+    out->d_taps = r.d_taps.as<float>();
+    out->d_hdr_bits = (flags & DTL_RX_WANT_HDR_BITS) ? r.d_hdr_bits.as<uint8_t>() : nullptr;
+    out->d_metric = (flags & DTL_RX_WANT_METRIC) ? r.d_metric.as<float>() : nullptr;
+    out->d_cw_bits = r.d_cw_bits.as<uint8_t>();
+    out->d_cw_nit = r.d_cw_nit.as<int32_t>();
+    for (int i = 0; i < 8; i++) out->stage_ms[i] = r.stage_ms[i];
+    out->frame_capacity = r.frame_capacity();
+    out->hdr_bits = r.cfg.header_len() * int(r.cfg.occupied_carriers[0].size());
+    out->frame_samples = r.frame_samples();
+    return DTL_OK;
+}
+
+int dtl_copy_device(void* dst, const void* src, size_t bytes, void* stream)
+{
+    if (!bytes) return DTL_OK;
+    if (!dst || !src) return DTL_ERR_INVALID_ARG;
+    DTL_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return DTL_OK;
+}
+
+int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, int64_t stream_len,
+                 int64_t* out, int64_t out_cap, int64_t* n_out)
+{
+    if (!n_out || (n_triggers && !triggers)) return DTL_ERR_INVALID_ARG;
+    dtl::FrameDetectState st;
+    st.frame_len = frame_len;
+    std::vector<int64_t> res = dtl::fix_sync_sparse(st, std::vector<int64_t>(triggers, triggers + n_triggers), stream_len);
+    *n_out = int64_t(res.size());
+    if (int64_t(res.size()) > out_cap) return DTL_ERR_CAPACITY;
+    std::copy(res.begin(), res.end(), out);
+    return DTL_OK;
+}
+
+int dtl_plateau_detect(const float* metric, int64_t n, float thr, int32_t max_len, int64_t* out, int64_t out_cap,
+                       int64_t* n_out)
+{
+    if (!metric || !n_out) return DTL_ERR_INVALID_ARG;
+    std::vector<unsigned long long> edges;
+    bool prev = false;
+    for (int64_t i = 0; i < n; i++) {
+        const bool cur = metric[i] >= thr;
+        if (cur != prev) edges.push_back((static_cast<unsigned long long>(i) << 1) | (cur ? 1ull : 0ull));
+        prev = cur;
+    }
+    std::vector<int64_t> res = dtl::plateau_from_edges(std::move(edges), n, max_len);
+    *n_out = int64_t(res.size());
+    if (int64_t(res.size()) > out_cap) return DTL_ERR_CAPACITY;
+    std::copy(res.begin(), res.end(), out);
+    return DTL_OK;
+}
+
+int dtl_feedback_sequence(int32_t n_mcs, const double* mcs_snr, const int32_t* mcs_cnst, const int32_t* mcs_fec,
+                          double hysteresis, int32_t decision_th, int32_t initial_mcs, const double* snr, int64_t n,
+                          int32_t* out_cnst, int32_t* out_fec)
+{
+    if (n_mcs <= 0 || !mcs_snr || !mcs_cnst || !mcs_fec || !snr || !out_cnst || !out_fec) return DTL_ERR_INVALID_ARG;
+    std::vector<dtl::McsEntry> lut;
+    for (int i = 0; i < n_mcs; i++) lut.push_back({ mcs_snr[i], mcs_cnst[i], mcs_fec[i] });
+    dtl::FeedbackDecision fb;
+    fb.init(lut, hysteresis, decision_th, initial_mcs);
+    for (int64_t i = 0; i < n; i++) fb.get(snr[i], &out_cnst[i], &out_fec[i]);
+    return DTL_OK;
 }
 
 } // extern "C"

@@ -73,7 +73,10 @@ __global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const floa
         for (int v = lane; v < t.n; v += kWave) {
             const int src = t.inv_perm[v];
             float val = kShortenedValue;
-            if (src < n_sent) val = (src < len0) ? llr[size_t(off0) + src] : llr[size_t(off1) + (src - len0)];
+            if (src < n_sent) {
+                if (src < len0) val = llr[size_t(off0) + src];
+                else val = (off1 != 0xFFFFFFFFu) ? llr[size_t(off1) + (src - len0)] : 0.0f; // soft bit never received
+            }
             const float y = -1 * val;
             ybuf[v] = y;
             est[v] = (y < 0) ? 1 : 0; // awgn_bp::compute_init_estimate

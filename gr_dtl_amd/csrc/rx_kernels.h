@@ -1,0 +1,28 @@
+// rx_kernels.h -- launchers of the receive-path kernels (rx_kernels.hip).
+#pragma once
+
+#include "dtl_common.h"
+#include "rx_types.h"
+
+namespace dtl {
+
+int launch_sync_edges(const cf32* iq, int64_t n, int fft_len, float threshold, unsigned long long* edges,
+                      unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st);
+int launch_trigger_angle(const cf32* iq, int64_t n, int fft_len, const int64_t* trig, int n_trig,
+                         float* angle, hipStream_t st);
+int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate* cands, int n_cand,
+                  const CfoSegment* segs, int n_segs, HeaderRec* recs, cf32* taps, uint8_t* hdr_bits,
+                  hipStream_t st);
+int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
+                   const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
+                   const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms,
+                   uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st);
+int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
+                    int stride, TbResult* res, int32_t* len, hipStream_t st);
+int launch_nofec_lengths(const int32_t* info, int n, int32_t* len, hipStream_t st);
+int launch_compact(const uint8_t* staging, int stride, const int32_t* len, int n, uint32_t* offs,
+                   uint32_t* total, uint8_t* out, hipStream_t st);
+size_t header_lds_bytes(const RxTables& t);
+size_t payload_lds_bytes(const RxTables& t);
+
+} // namespace dtl

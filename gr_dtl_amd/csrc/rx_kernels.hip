@@ -1,0 +1,726 @@
+// rx_kernels.hip -- HIP kernels (gfx950) of the adaptive-OFDM receive path, K1..K9/K11.
+//
+// Layout: the IQ stream stays where the caller put it (complex64, device).  One workgroup owns
+// one OFDM frame; its (2+h) preamble/header symbols (phase A) or its L payload symbols
+// (phase B) are pulled through LDS once: coalesced 8-byte loads (lane == sample), in-LDS
+// radix-2 FFT, then lane == subcarrier for channel estimation / equalisation / demapping.
+// No MFMA anywhere: nothing here is a dense contraction.
+//
+// Arithmetic follows the CPU reference chain (see each kernel); complex division is Smith's
+// algorithm and complex multiplication the 4-multiply form, both evaluated in float without
+// FMA contraction, i.e. exactly what libgcc's __divsc3/__mulsc3 give the reference's
+// std::complex<float> code on x86-64.
+#include "rx_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace dtl {
+
+namespace {
+
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b)
+{
+    return { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re };
+}
+__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return { a.re + b.re, a.im + b.im }; }
+__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return { a.re - b.re, a.im - b.im }; }
+__device__ __forceinline__ cf32 cscale(float s, cf32 a) { return { s * a.re, s * a.im }; }
+__device__ __forceinline__ cf32 cconj(cf32 a) { return { a.re, -a.im }; }
+__device__ __forceinline__ bool cnonzero(cf32 a) { return a.re != 0.0f || a.im != 0.0f; }
+
+// (a+ib)/(c+id), Smith's algorithm in float (libgcc __divsc3 for finite operands)
+__device__ __forceinline__ cf32 cdiv(cf32 x, cf32 y)
+{
+    const float a = x.re, b = x.im, c = y.re, d = y.im;
+    cf32 q;
+    if (fabsf(c) < fabsf(d)) {
+        const float r = c / d;
+        const float den = (c * r) + d;
+        q.re = ((a * r) + b) / den;
+        q.im = ((b * r) - a) / den;
+    } else {
+        const float r = d / c;
+        const float den = (d * r) + c;
+        q.re = ((b * r) + a) / den;
+        q.im = (b - (a * r)) / den;
+    }
+    return q;
+}
+
+__device__ __forceinline__ cf32 expj(float phase)
+{
+    float s, c;
+    sincosf(phase, &s, &c);
+    return { c, s };
+}
+
+constexpr double kPi = 3.14159265358979323846;
+
+// Oscillator phase at stream index i: frequency_modulator_fc(-2/N) integrating the held angle.
+__device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, int n_segs, int seg,
+                                           int64_t i, float sens)
+{
+    while (seg + 1 < n_segs && segs[seg + 1].start <= i) seg++;
+    double ph;
+    if (seg < 0 || segs[seg].start > i) {
+        ph = 0.0; // before the first trigger the held angle is 0
+    } else {
+        const CfoSegment s = segs[seg];
+        ph = s.phase0 + double(sens * s.angle) * double(i - s.start + 1);
+    }
+    ph = fmod(ph + kPi, 2.0 * kPi);
+    if (ph < 0) ph += 2.0 * kPi;
+    ph -= kPi;
+    return float(ph);
+}
+
+// Load OFDM symbol `sym` of the frame cut at `trigger` (delay N+cp, CP stripped, fine-CFO
+// derotated) into buf[] in bit-reversed order, then radix-2 DIT FFT in place.  blockDim.x == N.
+__device__ __forceinline__ void load_and_fft(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
+                                             int64_t trigger, int sym, const CfoSegment* segs, int n_segs,
+                                             int seg, cf32* buf)
+{
+    const int N = t.fft_len, P = N + t.cp_len;
+    const int tid = threadIdx.x;
+    // mixed[i] = r[i - (N+cp)] * osc[i]; symbol sample index i = trigger + sym*P + cp + tid
+    const int64_t i = trigger + int64_t(sym) * P + t.cp_len + tid;
+    const int64_t src = i - P;
+    cf32 v = { 0.0f, 0.0f };
+    if (src >= 0 && src < n_samples) v = iq[src];
+    const float sens = float(-2.0 / N);
+    const cf32 osc = expj(osc_phase(segs, n_segs, seg, i, sens));
+    buf[t.bitrev[tid]] = cmul(v, osc);
+    __syncthreads();
+    for (int len = 2; len <= N; len <<= 1) {
+        const int half = len >> 1;
+        if (tid < N / 2) {
+            const int grp = tid / half, k = tid - grp * half;
+            const int a = grp * len + k, b = a + half;
+            const cf32 w = t.twiddle[k * (N / len)];
+            const cf32 u = buf[a];
+            const cf32 vv = cmul(buf[b], w);
+            buf[a] = cadd(u, vv);
+            buf[b] = csub(u, vv);
+        }
+        __syncthreads();
+    }
+}
+
+// CRC of a byte string, MSB-first register, optional reflection (gr::digital::crc semantics)
+__device__ uint32_t crc_bits(const uint8_t* data, int len, int nbits, uint32_t poly, uint32_t init,
+                             uint32_t final_xor, bool refin, bool refout)
+{
+    const uint32_t top = 1u << (nbits - 1);
+    const uint32_t mask = (nbits == 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1);
+    uint32_t reg = init & mask;
+    for (int i = 0; i < len; i++) {
+        uint32_t byte = data[i];
+        if (refin) byte = __brev(byte) >> 24;
+        for (int b = 7; b >= 0; b--) {
+            const uint32_t inbit = (byte >> b) & 1u;
+            const uint32_t msb = (reg & top) ? 1u : 0u;
+            reg = (reg << 1) & mask;
+            if (msb ^ inbit) reg ^= poly;
+        }
+    }
+    if (refout) reg = __brev(reg) >> (32 - nbits);
+    return (reg ^ final_xor) & mask;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+// K1: Schmidl & Cox timing metric (GR ofdm_sync_sc_cfb as wired at ofdm_receiver.py:71-72).
+// Each thread slides the two windows over a strip of kStrip samples, sums in double, and emits
+// the threshold crossings ("edges") of the metric; plateau logic is sequential and runs on host.
+// ------------------------------------------------------------------------------------------
+constexpr int kSyncThreads = 256;
+
+__global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
+                                                                 int N, int strip, float thr,
+                                                                 unsigned long long* __restrict__ edges,
+                                                                 unsigned int* __restrict__ n_edges,
+                                                                 unsigned int max_edges,
+                                                                 float* __restrict__ metric_out)
+{
+    extern __shared__ cf32 tile[]; // N + strip*threads + 1 samples, tile[j] = iq[t0 - N - 1 + j]
+    const int half = N / 2;
+    const int64_t t0 = int64_t(blockIdx.x) * strip * kSyncThreads;
+    const int tile_len = N + 1 + strip * kSyncThreads;
+    for (int j = threadIdx.x; j < tile_len; j += kSyncThreads) {
+        const int64_t src = t0 - N - 1 + j;
+        cf32 v = { 0.0f, 0.0f };
+        if (src >= 0 && src < n) v = iq[src];
+        tile[j] = v;
+    }
+    __syncthreads();
+    const int64_t first = t0 + int64_t(threadIdx.x) * strip; // first output sample of this thread
+    if (first >= n) return;
+    // sample index m lives at tile[m - t0 + N + 1]
+    auto at = [&](int64_t m) -> cf32 { return tile[int(m - t0) + N + 1]; };
+    auto corr = [&](int64_t m) -> cf32 { // c[m] = r[m] * conj(r[m - N/2]) in float
+        const cf32 a = at(m), b = at(m - half);
+        return { a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im };
+    };
+    // window sums ending at sample first-1 (so the thread also knows the metric just before its strip)
+    double pr = 0, pi = 0, en = 0;
+    const int64_t n0 = first - 1;
+    for (int m = 0; m < half; m++) {
+        const cf32 c = corr(n0 - m);
+        pr += c.re; pi += c.im;
+    }
+    for (int m = 0; m < N; m++) {
+        const cf32 a = at(n0 - m);
+        en += 0.5f * (a.re * a.re + a.im * a.im);
+    }
+    auto metric_of = [&]() -> float {
+        const float Pr = float(-pr), Pi = float(-pi), E = float(en);
+        const float num = Pr * Pr + Pi * Pi;
+        return num / (E * E);
+    };
+    bool prev = (n0 >= 0) ? (metric_of() >= thr) : false;
+    for (int s = 0; s < strip; s++) {
+        const int64_t m = first + s;
+        if (m >= n) break;
+        const cf32 cn = corr(m), co = corr(m - half);
+        pr += cn.re; pr -= co.re;
+        pi += cn.im; pi -= co.im;
+        const cf32 a = at(m), o = at(m - N);
+        en += 0.5f * (a.re * a.re + a.im * a.im);
+        en -= 0.5f * (o.re * o.re + o.im * o.im);
+        const float mt = metric_of();
+        if (metric_out) metric_out[m] = mt;
+        const bool cur = mt >= thr;
+        if (cur != prev) {
+            const unsigned int slot = atomicAdd(n_edges, 1u);
+            if (slot < max_edges) edges[slot] = (static_cast<unsigned long long>(m) << 1) | (cur ? 1ull : 0ull);
+        }
+        prev = cur;
+    }
+}
+
+// K1b: arg(P) at each raw trigger (complex_to_arg + sample_and_hold_ff), one wave per trigger.
+__global__ __launch_bounds__(64) void trigger_angle_kernel(const cf32* __restrict__ iq, int64_t n, int N,
+                                                          const int64_t* __restrict__ trig, int n_trig,
+                                                          float* __restrict__ angle)
+{
+    const int half = N / 2;
+    const int w = blockIdx.x;
+    if (w >= n_trig) return;
+    const int64_t pos = trig[w];
+    double pr = 0, pi = 0;
+    for (int m = threadIdx.x; m < half; m += 64) {
+        const int64_t a_i = pos - m, b_i = pos - m - half;
+        cf32 a = { 0, 0 }, b = { 0, 0 };
+        if (a_i >= 0 && a_i < n) a = iq[a_i];
+        if (b_i >= 0 && b_i < n) b = iq[b_i];
+        pr += double(a.re * b.re + a.im * b.im);
+        pi += double(a.im * b.re - a.re * b.im);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        pr += __shfl_down(pr, off);
+        pi += __shfl_down(pi, off);
+    }
+    if (threadIdx.x == 0) angle[w] = atan2f(float(-pi), float(-pr));
+}
+
+// ------------------------------------------------------------------------------------------
+// Phase A (K2..K5): per trigger -- cut (2+h) symbols, FFT, ofdm_chanest_vcvc, header equaliser
+// (ofdm_frame_equalizer_vcvc around ofdm_adaptive_header_equalizer, alpha == 1), serializer,
+// BPSK slicer, ofdm_adaptive_packet_header::header_parser.
+// ------------------------------------------------------------------------------------------
+__global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
+                              const Candidate* __restrict__ cands, const CfoSegment* __restrict__ segs,
+                              int n_segs, HeaderRec* __restrict__ recs, cf32* __restrict__ taps_out,
+                              uint8_t* __restrict__ hdr_bits_out)
+{
+    extern __shared__ unsigned char smem_raw[];
+    const int N = t.fft_len, h = t.header_len, tid = threadIdx.x;
+    cf32* Y = reinterpret_cast<cf32*>(smem_raw);            // (2+h) x N, natural (unshifted) order
+    cf32* H = Y + size_t(2 + h) * N;                        // N taps (shifted positions)
+    float* gabs = reinterpret_cast<float*>(H + N);          // N/2+2 |B(g)| values
+    uint8_t* bits = reinterpret_cast<uint8_t*>(gabs + N / 2 + 2); // hdr_bits
+    __shared__ int s_off;
+
+    const Candidate cd = cands[blockIdx.x];
+    for (int s = 0; s < 2 + h; s++)
+        load_and_fft(t, iq, n_samples, cd.trigger, s, segs, n_segs, cd.seg, Y + size_t(s) * N);
+    // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N]
+    auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + ((k + N / 2) & (N - 1))]; };
+
+    // get_carr_offset: B(g) = sum_k conj(y1[k+g]) * conj(corr_v[k]) * y2[k+g], first maximum wins
+    const int n_g = (t.g_max - t.g_min) / 2 + 1;
+    for (int gi = tid; gi < n_g; gi += blockDim.x) {
+        const int g = t.g_min + 2 * gi;
+        cf32 acc = { 0.0f, 0.0f };
+        for (int k = 0; k < N; k++) {
+            const cf32 cv = t.corr_v[k];
+            if (cnonzero(cv)) acc = cadd(acc, cmul(cmul(cconj(ysh(0, k + g)), cconj(cv)), ysh(1, k + g)));
+        }
+        gabs[gi] = hypotf(acc.re, acc.im);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        float bmax = 0.0f;
+        for (int gi = 0; gi < n_g; gi++)
+            if (gabs[gi] > bmax) { bmax = gabs[gi]; best = t.g_min + 2 * gi; }
+        s_off = best;
+    }
+    __syncthreads();
+    const int off = s_off;
+    // get_chan_taps
+    {
+        const int j = tid; // tap index
+        cf32 tap = { 0.0f, 0.0f };
+        const int lo = off > 0 ? 0 : -off, hi = off > 0 ? N - off : N;
+        const cf32 r = t.ref_sym[j];
+        if (j >= lo && j < hi && cnonzero(r)) tap = cdiv(ysh(1, j + off), r);
+        H[j] = tap;
+    }
+    __syncthreads();
+    // header symbols: integer-CFO shift on the flattened frame, phase derotation, one-tap equalise
+    const int total = h * N;
+    int bit_base = 0;
+    for (int i = 0; i < h; i++) {
+        const int set = i % t.n_occ_sets;
+        const int nocc = t.occ_len[set];
+        for (int r = tid; r < nocc; r += blockDim.x) {
+            const int k = t.occ_idx[set * t.max_occ + r];
+            const int p = i * N + k, src = p + off;
+            cf32 v = { 0.0f, 0.0f };
+            if (off < 0 ? (p >= -off) : (p < total - off)) v = ysh(2 + src / N, src % N);
+            const float ph = float(-(2.0 * kPi) * off * t.cp_len / N * (i + 1));
+            v = cmul(v, expj(ph));
+            const cf32 eq = cdiv(v, H[k]);
+            bits[bit_base + r] = eq.re > 0 ? 1 : 0; // constellation_bpsk::decision_maker
+        }
+        bit_base += nocc;
+    }
+    __syncthreads();
+    // taps handed to the payload equaliser: state after the header, rotated (GR :"Update the
+    // channel state regarding the frequency offset")
+    {
+        const float ph = float((2.0 * kPi) * off * t.cp_len / N * h);
+        taps_out[size_t(blockIdx.x) * N + tid] = cmul(H[tid], expj(ph));
+    }
+    if (hdr_bits_out)
+        for (int b = tid; b < t.hdr_bits; b += blockDim.x) hdr_bits_out[size_t(blockIdx.x) * t.hdr_bits + b] = bits[b];
+    if (tid == 0) {
+        // header_parser (packet_header.cc:231-312), bits_per_byte == 1
+        HeaderRec r{};
+        const int HL = t.hdr_bits;
+        int k = 0;
+        auto field = [&](int nb) { int v = 0; for (int i = 0; i < nb && k < HL; i++, k++) v |= (bits[k] & 1) << i; return v; };
+        r.payload_len = field(12);
+        r.frame_no = field(12);
+        r.cnst = field(4);
+        r.fb_cnst = field(4);
+        if (t.has_fec) {
+            r.tb_no = field(12); r.fec_fb = field(4); r.tb_offset = field(12); r.fec = field(4); r.tb_payload = field(16);
+        }
+        // pack_crc (:93-105) keeps the reference's loop bound i*len+j < header_len
+        uint8_t* crc_buf = reinterpret_cast<uint8_t*>(gabs); // gabs is dead; (HL-16)/8+1 <= N/2*4 bytes
+        int len = (HL - 16) / 8;
+        if ((HL - 16) % 8) ++len;
+        for (int i = 0; i < len; i++) {
+            uint8_t v = 0;
+            for (int j = 0; j < 8 && i * len + j < HL; j++) v = uint8_t((v << 1) | (bits[i * 8 + j] & 1));
+            crc_buf[i] = v;
+        }
+        const uint32_t crc = crc_bits(crc_buf, len, 16, 0x1021u, 0xFFFFu, 0u, false, true);
+        int ok = 1;
+        for (int i = 0; i < 16 && k < HL; i++, k++)
+            if (uint32_t(bits[k] & 1) != ((crc >> i) & 1u)) ok = 0;
+        r.crc_ok = ok;
+        r.carr_offset = off;
+        recs[blockIdx.x] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Phase B (K2,K3,K6,K7,K8): per accepted frame -- cut L payload symbols, FFT,
+// ofdm_adaptive_frame_equalizer_vcvc_impl::work (:152-193) + frame_equalize
+// (ofdm_adaptive_equalizer.cc:217-268) + mpsk_snr_est_simple, ofdm_serializer_vcc and
+// ofdm_adaptive_constellation_soft_cf (soft_cf_impl.cc:89-148) or the hard demapper of the
+// no-FEC tail.
+// ------------------------------------------------------------------------------------------
+struct Welford {
+    double n, mean, m2;
+};
+
+__device__ __forceinline__ Welford welford_merge(Welford a, Welford b)
+{
+    if (b.n == 0) return a;
+    if (a.n == 0) return b;
+    const double n = a.n + b.n, d = b.mean - a.mean;
+    return { n, a.mean + d * (b.n / n), a.m2 + b.m2 + d * d * (a.n * b.n / n) };
+}
+
+__global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
+                               const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
+                               int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
+                               const uint32_t* __restrict__ llr_off, float* __restrict__ llr_out,
+                               cf32* __restrict__ eq_hard, cf32* __restrict__ eq_soft,
+                               cf32* __restrict__ soft_syms, uint8_t* __restrict__ nofec_bytes,
+                               int32_t* __restrict__ nofec_info, int nofec_stride)
+{
+    extern __shared__ unsigned char smem_raw[];
+    const int N = t.fft_len, L = t.frame_length, tid = threadIdx.x, h = t.header_len;
+    cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // N : FFT scratch
+    cf32* frame = buf + N;                            // L x N : shifted/derotated FFT output -> soft symbols
+    Welford* wred = reinterpret_cast<Welford*>(frame + size_t(L) * N); // blockDim/64 partials
+    __shared__ FrameStat s_stat;
+
+    const FrameDesc fd = frames[blockIdx.x];
+    const int off = fd.carr_offset;
+    const int total = L * N;
+
+    // zero fill of the integer-CFO shift (:154-166)
+    if (off < 0) { for (int p = tid; p < -off; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
+    else { for (int p = total - off + tid; p < total; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
+    for (int i = 0; i < L; i++) {
+        load_and_fft(t, iq, n_samples, fd.trigger, 2 + h + i, segs, n_segs, fd.seg, buf);
+        // out[p - off] = in[p], then out *= expj(-2 pi off cp / N (sym+1)) with sym of the destination
+        const int p = i * N + tid;
+        const int dst = p - off;
+        if (dst >= 0 && dst < total) {
+            const cf32 v = buf[(tid + N / 2) & (N - 1)];
+            const float ph = float(-(2.0 * kPi) * off * t.cp_len / N * (dst / N + 1));
+            frame[dst] = cmul(v, expj(ph));
+        }
+        __syncthreads();
+    }
+
+    // frame_equalize: lane == subcarrier, sequential over the L symbols
+    const int k = tid;
+    cf32 Hk = taps_in[size_t(fd.cand) * N + k];
+    const float alpha = t.eq_alpha;
+    const bool occupied = t.occupied[k] != 0;
+    const cf32* pts = t.cnst_pts + fd.cnst * 16;
+    Welford w = { 0.0, 0.0, 0.0 };
+    int pilot_carr_set = t.n_pilot_sets ? h % t.n_pilot_sets : 0;
+    cf32* hard_row = eq_hard ? eq_hard + size_t(blockIdx.x) * total : nullptr;
+    cf32* soft_row = eq_soft ? eq_soft + size_t(blockIdx.x) * total : nullptr;
+    for (int i = 0; i < L; i++) {
+        const int pset = (h + i) % t.n_pilot_sym_sets;
+        const bool is_pilot = t.n_pilot_sets && t.pilot_mask[pilot_carr_set * N + k];
+        const cf32 y = frame[i * N + k];
+        cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
+        if (is_pilot) {
+            const cf32 pv = t.pilot_val[pset * N + k];
+            const cf32 pilot_eq = cdiv(y, Hk);
+            // mpsk_snr_est_simple::update on |pilot_eq| (Welford, double)
+            const double x = double(hypotf(pilot_eq.re, pilot_eq.im));
+            w.n += 1.0;
+            const double d = x - w.mean;
+            w.mean += d / w.n;
+            w.m2 += d * (x - w.mean);
+            Hk = cadd(cscale(alpha, Hk), cdiv(cscale(1 - alpha, y), pv));
+            hard_v = pv;
+        } else if (occupied) {
+            const cf32 sym_eq = cdiv(y, Hk);
+            unsigned idx;
+            switch (fd.cnst) { // decision_maker of each GR constellation
+            case 1: idx = sym_eq.re > 0; break;
+            case 2: idx = 2 * (sym_eq.im > 0) + (sym_eq.re > 0); break;
+            case 3: idx = (fabsf(sym_eq.re) <= fabsf(sym_eq.im) ? 4u : 0u) | (sym_eq.re <= 0 ? 1u : 0u) | (sym_eq.im <= 0 ? 2u : 0u); break;
+            default: {
+                const float level = sqrtf(0.1f);
+                idx = (sym_eq.im > 0 ? 8u : 0u) | (sym_eq.re < 0 ? 4u : 0u) | (fabsf(sym_eq.re) > 2 * level ? 2u : 0u) | (fabsf(sym_eq.im) > 2 * level ? 1u : 0u);
+            } break;
+            }
+            const cf32 sym_est = pts[idx];
+            Hk = cadd(cscale(alpha, Hk), cdiv(cscale(1 - alpha, y), sym_est));
+            hard_v = sym_est;
+            soft_v = sym_eq;
+        }
+        if (hard_row) hard_row[i * N + k] = hard_v;
+        if (soft_row) soft_row[i * N + k] = soft_v;
+        frame[i * N + k] = soft_v; // the serializer / demapper read the soft output
+        if (t.n_pilot_sets) pilot_carr_set = (pilot_carr_set + 1) % t.n_pilot_sets;
+    }
+    // combine the per-carrier Welford states (Chan); double, fixed tree order
+    for (int o = 32; o > 0; o >>= 1) {
+        Welford other = { __shfl_down(w.n, o), __shfl_down(w.mean, o), __shfl_down(w.m2, o) };
+        w = welford_merge(w, other);
+    }
+    if ((tid & 63) == 0) wred[tid >> 6] = w;
+    __syncthreads();
+    if (tid == 0) {
+        Welford a = wred[0];
+        for (int i = 1; i < int(blockDim.x + 63) / 64; i++) a = welford_merge(a, wred[i]);
+        // mpsk_snr_est_simple::snr()/noise(); get_noise() (equalizer.cc:279-287)
+        const double signal_db = 10.0 * log10(fabs(a.mean * a.mean));
+        const double noise_db = 10.0 * log10(2.0 * a.m2 / a.n);
+        s_stat = { signal_db - noise_db, noise_db, pow(10.0, noise_db / 10.0) };
+        stats[blockIdx.x] = s_stat;
+    }
+    __syncthreads();
+    if (fd.n_syms <= 0) return; // payload == 0: frame dropped after the equaliser (:218,254)
+
+    // ofdm_serializer_vcc (symbols_skipped = 1) + soft / hard demapper
+    const int bps = fd.cnst == 4 ? 4 : fd.cnst; // 1,2,3,4
+    const int M = 1 << bps;
+    const float npwr = float(sqrt(s_stat.noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
+    uint8_t* hard_syms = reinterpret_cast<uint8_t*>(buf); // no-FEC: symbol values (<= N*8 bytes available)
+    int q_base = 0;
+    for (int i = 0; i < L && q_base < fd.n_syms; i++) {
+        const int set = (1 + i) % t.n_occ_sets;
+        const int nocc = t.occ_len[set];
+        for (int r = tid; r < nocc; r += blockDim.x) {
+            const int q = q_base + r;
+            if (q >= fd.n_syms) continue;
+            const cf32 s = frame[i * N + t.occ_idx[set * t.max_occ + r]];
+            if (soft_syms) soft_syms[size_t(blockIdx.x) * t.frame_capacity + q] = s;
+            if (t.has_fec) {
+                // constellation::calc_soft_dec then reversed to LSB-first
+                float p0[kMaxBps] = { 0, 0, 0, 0 }, p1[kMaxBps] = { 0, 0, 0, 0 };
+                for (int m = 0; m < M; m++) {
+                    const float dr = s.re - pts[m].re, di = s.im - pts[m].im;
+                    const float dist = t.llr_dist_mode ? hypotf(dr, di) : (dr * dr + di * di);
+                    const float d = expf(-dist / npwr);
+#pragma unroll
+                    for (int j = 0; j < kMaxBps; j++) {
+                        if (j < bps) { if ((m >> j) & 1) p1[j] += d; else p0[j] += d; }
+                    }
+                }
+                float* o = llr_out + size_t(llr_off[blockIdx.x]) + size_t(q) * bps;
+#pragma unroll
+                for (int j = 0; j < kMaxBps; j++)
+                    if (j < bps) o[j] = logf(p1[j]) - logf(p0[j]);
+            }
+        }
+        q_base += nocc;
+    }
+    if (!t.has_fec) {
+        // no-FEC tail: ofdm_adaptive_constellation_decoder_cb + ofdm_adaptive_frame_pack_bb; the soft
+        // symbols are sliced with the same decision makers, repacked bps -> 8 LSB first, CRC-32 checked.
+        // (buf holds at most N*8 bytes: frames of up to N*8 symbols are sliced in one pass.)
+        __syncthreads();
+        uint8_t* bytes = nofec_bytes + size_t(blockIdx.x) * nofec_stride;
+        const int n_bits = fd.n_syms * bps;
+        int n_written = n_bits / 8 + ((n_bits % 8) ? 1 : 0);
+        if (n_bits % 8) --n_written;
+        for (int b = tid; b < n_written; b += blockDim.x) {
+            unsigned v = 0;
+            for (int j = 0; j < 8; j++) {
+                const int bit = b * 8 + j, q = bit / bps, jb = bit % bps;
+                // locate symbol q: data carriers per OFDM symbol may differ per set
+                int i = 0, base = 0;
+                while (true) { const int nocc = t.occ_len[(1 + i) % t.n_occ_sets]; if (q < base + nocc) break; base += nocc; i++; }
+                const int set = (1 + i) % t.n_occ_sets;
+                const cf32 s = frame[i * N + t.occ_idx[set * t.max_occ + (q - base)]];
+                unsigned idx;
+                switch (fd.cnst) {
+                case 1: idx = s.re > 0; break;
+                case 2: idx = 2 * (s.im > 0) + (s.re > 0); break;
+                case 3: idx = (fabsf(s.re) <= fabsf(s.im) ? 4u : 0u) | (s.re <= 0 ? 1u : 0u) | (s.im <= 0 ? 2u : 0u); break;
+                default: { const float level = sqrtf(0.1f);
+                    idx = (s.im > 0 ? 8u : 0u) | (s.re < 0 ? 4u : 0u) | (fabsf(s.re) > 2 * level ? 2u : 0u) | (fabsf(s.im) > 2 * level ? 1u : 0u); } break;
+                }
+                v |= ((idx >> jb) & 1u) << j;
+            }
+            bytes[b] = uint8_t(v);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int ok = 0;
+            if (n_written >= 4) {
+                const uint32_t crc = crc_bits(bytes, n_written - 4, 32, 0x04C11DB7u, 0xFFFFFFFFu, 0xFFFFFFFFu, true, true);
+                ok = 1;
+                for (int i = 0; i < 4; i++) if (bytes[n_written - 4 + i] != ((crc >> (8 * i)) & 0xFF)) ok = 0;
+            }
+            nofec_info[2 * blockIdx.x] = ok;
+            nofec_info[2 * blockIdx.x + 1] = n_written;
+        }
+        (void)hard_syms;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K11: per transport block -- repack decoded bits to bytes (LSB first), CRC-32 verify
+// (ofdm_adaptive_fec_decoder_impl.cc:161-181), average iteration count (tb_decoder.cc:191).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__ tbs, int n_tbs,
+                                                     const uint8_t* __restrict__ bits,
+                                                     const int32_t* __restrict__ nit,
+                                                     uint8_t* __restrict__ staging, int stride,
+                                                     TbResult* __restrict__ res)
+{
+    const int tb = blockIdx.x;
+    if (tb >= n_tbs) return;
+    const TbDesc d = tbs[tb];
+    uint8_t* bytes = staging + size_t(tb) * stride;
+    const int n_bytes = int(d.n_bits / 8);
+    for (int b = threadIdx.x; b < n_bytes; b += 64) {
+        unsigned v = 0;
+        for (int j = 0; j < 8; j++) v |= unsigned(bits[size_t(d.bits_off) + b * 8 + j] & 1) << j;
+        bytes[b] = uint8_t(v);
+    }
+    int it_sum = 0;
+    for (unsigned c = threadIdx.x; c < d.n_cw; c += 64) it_sum += nit[d.cw_first + c];
+    for (int o = 32; o > 0; o >>= 1) it_sum += __shfl_down(it_sum, o);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TbResult r{};
+        r.user_bits = int(d.n_bits) - 32;
+        r.avg_it = d.n_cw ? it_sum / int(d.n_cw) : 0;
+        int ok = 0;
+        if (n_bytes >= 4) {
+            const uint32_t crc = crc_bits(bytes, n_bytes - 4, 32, 0x04C11DB7u, 0xFFFFFFFFu, 0xFFFFFFFFu, true, true);
+            ok = 1;
+            for (int i = 0; i < 4; i++) if (bytes[n_bytes - 4 + i] != ((crc >> (8 * i)) & 0xFF)) ok = 0;
+        }
+        r.crc_ok = ok;
+        res[tb] = r;
+    }
+}
+
+// Exclusive scan of the per-block output lengths (single workgroup; block counts are O(frames)).
+__global__ __launch_bounds__(1024) void scan_lengths_kernel(const int32_t* __restrict__ len, int n,
+                                                           uint32_t* __restrict__ offs,
+                                                           uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = min(n, lo + per);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += uint32_t(len[i]);
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t v = (tid >= o) ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int i = lo; i < hi; i++) { offs[i] = run; run += uint32_t(len[i]); }
+    if (tid == 1023) *total = part[1023];
+}
+
+__global__ void compact_kernel(const uint8_t* __restrict__ staging, int stride, const int32_t* __restrict__ len,
+                               const uint32_t* __restrict__ offs, int n, uint8_t* __restrict__ out)
+{
+    const int b = blockIdx.x;
+    if (b >= n) return;
+    const int l = len[b];
+    const uint8_t* src = staging + size_t(b) * stride;
+    uint8_t* dst = out + offs[b];
+    for (int i = threadIdx.x; i < l; i += blockDim.x) dst[i] = src[i];
+}
+
+// per-block output length: user bytes of a CRC-ok TB (FEC) or n_written-4 of every frame (no FEC)
+__global__ void tb_lengths_kernel(const TbResult* __restrict__ res, int n, int32_t* __restrict__ len)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) len[i] = res[i].crc_ok ? res[i].user_bits / 8 : 0;
+}
+__global__ void nofec_lengths_kernel(const int32_t* __restrict__ info, int n, int32_t* __restrict__ len)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) len[i] = info[2 * i + 1] >= 4 ? info[2 * i + 1] - 4 : 0;
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+int launch_sync_edges(const cf32* iq, int64_t n, int N, float thr, unsigned long long* edges,
+                      unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st)
+{
+    // strip: work per thread; tile = N + 1 + strip*256 samples of 8 bytes must fit LDS comfortably
+    int strip = N <= 64 ? 16 : 32;
+    const size_t lds = size_t(N + 1 + strip * kSyncThreads) * sizeof(cf32);
+    const int64_t per_block = int64_t(strip) * kSyncThreads;
+    const int64_t grid = (n + per_block - 1) / per_block;
+    if (grid <= 0) return DTL_OK;
+    hipLaunchKernelGGL(sync_edges_kernel, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, N, strip, thr,
+                       edges, n_edges, max_edges, metric_out);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+int launch_trigger_angle(const cf32* iq, int64_t n, int N, const int64_t* trig, int n_trig, float* angle,
+                         hipStream_t st)
+{
+    if (n_trig <= 0) return DTL_OK;
+    hipLaunchKernelGGL(trigger_angle_kernel, dim3(n_trig), dim3(64), 0, st, iq, n, N, trig, n_trig, angle);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+size_t header_lds_bytes(const RxTables& t)
+{
+    size_t b = size_t(2 + t.header_len) * t.fft_len * sizeof(cf32) + size_t(t.fft_len) * sizeof(cf32) +
+               size_t(t.fft_len / 2 + 2) * sizeof(float) + size_t(t.hdr_bits);
+    return (b + 15) & ~size_t(15);
+}
+
+int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate* cands, int n_cand,
+                  const CfoSegment* segs, int n_segs, HeaderRec* recs, cf32* taps, uint8_t* hdr_bits,
+                  hipStream_t st)
+{
+    if (n_cand <= 0) return DTL_OK;
+    hipLaunchKernelGGL(header_kernel, dim3(n_cand), dim3(t.fft_len), header_lds_bytes(t), st, t, iq, n, cands,
+                       segs, n_segs, recs, taps, hdr_bits);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+size_t payload_lds_bytes(const RxTables& t)
+{
+    size_t b = size_t(t.fft_len) * sizeof(cf32) + size_t(t.frame_length) * t.fft_len * sizeof(cf32) +
+               size_t((t.fft_len + 63) / 64) * sizeof(Welford);
+    return (b + 15) & ~size_t(15);
+}
+
+int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
+                   const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
+                   const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms,
+                   uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st)
+{
+    if (n_frames <= 0) return DTL_OK;
+    const size_t lds = payload_lds_bytes(t);
+    if (lds > 160 * 1024) { set_last_error("payload kernel: frame does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(payload_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(payload_kernel, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
+                       taps, stats, llr_off, llr, eq_hard, eq_soft, soft_syms, nofec_bytes, nofec_info,
+                       nofec_stride);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
+                    int stride, TbResult* res, int32_t* len, hipStream_t st)
+{
+    if (n_tbs <= 0) return DTL_OK;
+    hipLaunchKernelGGL(tb_check_kernel, dim3(n_tbs), dim3(64), 0, st, tbs, n_tbs, bits, nit, staging, stride, res);
+    hipLaunchKernelGGL(tb_lengths_kernel, dim3((n_tbs + 255) / 256), dim3(256), 0, st, res, n_tbs, len);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+int launch_nofec_lengths(const int32_t* info, int n, int32_t* len, hipStream_t st)
+{
+    if (n <= 0) return DTL_OK;
+    hipLaunchKernelGGL(nofec_lengths_kernel, dim3((n + 255) / 256), dim3(256), 0, st, info, n, len);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+int launch_compact(const uint8_t* staging, int stride, const int32_t* len, int n, uint32_t* offs,
+                   uint32_t* total, uint8_t* out, hipStream_t st)
+{
+    if (n <= 0) { DTL_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint32_t), st)); return DTL_OK; }
+    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, len, n, offs, total);
+    hipLaunchKernelGGL(compact_kernel, dim3(n), dim3(128), 0, st, staging, stride, len, offs, n, out);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+} // namespace dtl

@@ -1,0 +1,799 @@
+// rx_pipeline.cpp -- host orchestration of the batched receive path.
+//
+// The reference runs these steps as single-threaded GNU Radio blocks passing tags/messages; here
+// the O(samples) arithmetic lives in HIP kernels (rx_kernels.hip, ldpc_bp.hip) and the O(frames)
+// integer control logic -- which is inherently sequential and must be bit-exact -- runs on the
+// host between kernel phases:
+//   plateau_detector_fb            (GR, via ofdm_sync_sc_cfb)           -> plateau_from_edges
+//   ofdm_adaptive_frame_detect_bb  (lib/dtl/..._frame_detect_bb_impl.cc) -> fix_sync_sparse
+//   header_payload_demux + header_parser state (packet_header.cc:269-273) -> demux walk
+//   tb_decoder::process_frame/decode (lib/dtl/tb_decoder.cc)            -> TbAssembler (gather tables)
+//   ofdm_adaptive_feedback_decision + lost-frame counters               -> after phase B
+#include "rx_pipeline.h"
+
+#include "rx_kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <set>
+
+namespace dtl {
+
+// ------------------------------------------------------------------ small helpers
+
+DevBuf::~DevBuf()
+{
+    if (p) (void)hipFree(p);
+}
+
+int DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap && p) return DTL_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    DTL_HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+    return DTL_OK;
+}
+
+static int bits_per_symbol(int cnst) { return (cnst >= 1 && cnst <= 4) ? cnst : 0; }
+static int compute_tb_len(int cw_len, int frame_len) { return frame_len > cw_len ? 1 + frame_len / cw_len : 1; }
+static int align_bits_to_bytes(int nbits) { return nbits / 8 + ((nbits % 8) ? 1 : 0); }
+
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ plateau detector
+
+std::vector<int64_t> plateau_from_edges(std::vector<unsigned long long> edges, int64_t n, int max_len)
+{
+    std::sort(edges.begin(), edges.end());
+    // intervals [start, end) where metric >= threshold
+    std::vector<std::pair<int64_t, int64_t>> runs;
+    int64_t open = -1;
+    for (unsigned long long e : edges) {
+        const int64_t pos = int64_t(e >> 1);
+        if (e & 1ull) { if (open < 0) open = pos; }
+        else if (open >= 0) { runs.emplace_back(open, pos); open = -1; }
+    }
+    if (open >= 0) runs.emplace_back(open, n);
+    std::vector<int64_t> trig;
+    int64_t i = 0;
+    size_t r = 0;
+    while (i < n && r < runs.size()) {
+        while (r < runs.size() && runs[r].second <= i) r++; // runs entirely behind the scan position
+        if (r >= runs.size()) break;
+        const int64_t flank_start = std::max(i, runs[r].first);
+        i = runs[r].second; // first sample below threshold (or n)
+        if (i - flank_start > 1) { // "1 sample is not a plateau"
+            trig.push_back(flank_start + (i - flank_start) / 2);
+            i = std::min(i + max_len, n - 1);
+        }
+        i++; // the for loop's increment
+    }
+    return trig;
+}
+
+// ------------------------------------------------------------------ frame_detect_bb::fix_sync
+
+std::vector<int64_t> fix_sync_sparse(FrameDetectState& s, const std::vector<int64_t>& triggers, int64_t len)
+{
+    constexpr int kSyncedTh = 3, kMaxMissing = 5; // :21-22
+    constexpr int64_t INF = std::numeric_limits<int64_t>::max();
+    std::set<int64_t> out(triggers.begin(), triggers.end());
+    int64_t last_trigger_index = -int64_t(s.remainder);
+    bool trigger_found = false;
+    int64_t i = 0, index = s.remainder;
+    const int64_t FL = s.frame_len;
+    while (i < len) {
+        auto it = out.lower_bound(i);
+        const int64_t t = (it != out.end() && *it < len) ? *it : INF;
+        int64_t miss = INF;
+        if (s.in_sync) {
+            miss = i + std::max<int64_t>(0, (FL + 11) - index);
+            if (index + (len - 1 - i) > FL + 1) miss = std::min(miss, len - 1);
+            if (miss >= len) miss = INF;
+        }
+        const int64_t ev = std::min(t, miss);
+        if (ev == INF) break;
+        index += ev - i;
+        i = ev;
+        if (t == ev) {
+            const int64_t diff = (i - last_trigger_index) - FL;
+            index = 0;
+            if (s.acc_error) ++s.trigger_counter;
+            const int64_t inst_error = diff < 0 ? -diff : diff;
+            if (inst_error == 1) s.acc_error += int(diff);
+            s.error_count += inst_error != 0;
+            if (inst_error == 0 || inst_error == 1) {
+                if (s.synced < kSyncedTh) ++s.synced;
+                else s.in_sync = true;
+            } else {
+                s.synced = 0;
+                s.in_sync = false;
+            }
+            if (s.acc_error > 1 || (inst_error > 1 && inst_error < 10)) {
+                if (last_trigger_index + FL < len) {
+                    out.erase(i);
+                    last_trigger_index += FL;
+                    if (last_trigger_index >= 0) out.insert(last_trigger_index);
+                    i = last_trigger_index;
+                    s.acc_error = 0;
+                    ++s.correction_count;
+                } else {
+                    last_trigger_index = i;
+                }
+            } else {
+                last_trigger_index = i;
+            }
+            s.remainder = int(len - last_trigger_index);
+            trigger_found = true;
+            if (s.trigger_counter > 10) s.acc_error = 0;
+        } else {
+            last_trigger_index += FL;
+            if (last_trigger_index >= 0) out.insert(last_trigger_index);
+            i = last_trigger_index;
+            index = 0;
+            trigger_found = true;
+            s.remainder = int(len - last_trigger_index);
+            ++s.missing_count;
+            if (--s.synced < kSyncedTh - kMaxMissing) {
+                s.in_sync = false;
+                s.synced = 0;
+            }
+        }
+        ++i;
+        ++index;
+    }
+    if (!trigger_found) s.remainder += int(len);
+    std::vector<int64_t> res;
+    for (int64_t p : out)
+        if (p >= 0 && p < len) res.push_back(p);
+    return res;
+}
+
+// ------------------------------------------------------------------ feedback decision
+
+void FeedbackDecision::init(const std::vector<McsEntry>& mcs, double hyst, int th, int initial)
+{
+    lut = mcs;
+    if (lut.empty()) lut.push_back({ 0.0, 1, 0 });
+    lut[0].snr_th = DBL_MIN; // feedback_decision.cc:50
+    hysteresis = hyst;
+    decision_th = th;
+    counter = 0;
+    last = pending = std::min<int>(std::max(initial, 0), int(lut.size()) - 1);
+}
+
+void FeedbackDecision::get(double snr, int* cnst, int* fec)
+{
+    auto update = [&](int id) {
+        if (id != pending) { counter = 0; pending = id; }
+        else if (++counter >= decision_th) { counter = 0; last = pending; }
+    };
+    const int cur = last;
+    if (snr < lut[cur].snr_th) update(cur > 0 ? cur - 1 : 0); // reference asserts cur > 0 (:66)
+    else if (cur + 1 < int(lut.size())) {
+        if (snr > lut[cur + 1].snr_th + hysteresis) update(cur + 1);
+        else counter = 0;
+    } else counter = 0;
+    *cnst = lut[last].cnst;
+    *fec = lut[last].fec;
+}
+
+// ------------------------------------------------------------------ transport-block reassembly
+
+namespace {
+
+struct Seg {
+    uint32_t off;
+    int len;
+};
+
+// tb_decoder (lib/dtl/tb_decoder.cc) with the receive buffer expressed as source segments of the
+// soft-bit stream instead of copied floats.
+struct TbAssembler {
+    struct PendingTb {
+        int code;               // decoder index
+        int tb_no, tb_payload;  // as reported by on_data_ready
+        uint32_t n_bits;
+        std::vector<CwDesc> cws; // out_off relative to the TB's first bit
+    };
+    std::vector<Seg> rcv;
+    long rcv_size = 0, rcv_cap = 0, buf_idx = 0;
+    int tb_number = -1;
+    bool have_info = false;
+    int info_tb_payload = 0, info_code = 0;
+    std::vector<PendingTb> done;
+
+    void append(uint32_t base, long lo, long hi, long in_len)
+    {
+        if (hi <= lo) return;
+        // reads past the frame's soft bits (reference: whatever follows in the buffer) are
+        // defined as "never received": a gap segment, decoded as soft value 0
+        long h2 = std::min(hi, in_len);
+        if (h2 > lo) rcv.push_back({ uint32_t(base + lo), int(h2 - lo) });
+        if (hi > std::max(h2, lo)) rcv.push_back({ 0xFFFFFFFFu, int(hi - std::max(h2, lo)) });
+        rcv_size += hi - lo;
+    }
+    void clear() { rcv.clear(); rcv_size = 0; }
+
+    void decode(int tb_len, int n, int k, int tb_no, int tb_payload)
+    {
+        PendingTb tb;
+        tb.code = info_code; tb.tb_no = tb_no; tb.tb_payload = tb_payload;
+        tb.n_bits = uint32_t(std::max(info_tb_payload, 0));
+        const int ncheck = n - k;
+        int payload_len = info_tb_payload;
+        long rcv_idx = 0;
+        uint32_t d_idx = 0;
+        size_t si = 0; long seg_start = 0; // segment cursor
+        for (int i = 0; i < tb_len; ++i) {
+            int k_ = payload_len / (tb_len - i);
+            if (payload_len % (tb_len - i)) ++k_;
+            payload_len -= k_;
+            const int k_used = std::min(std::max(k_, 0), k);
+            const long want = ncheck + k_used;
+            CwDesc d{};
+            d.out_off = d_idx;
+            d.k_used = uint16_t(k_used);
+            // locate rcv_idx in the segment list
+            while (si < rcv.size() && seg_start + rcv[si].len <= rcv_idx) { seg_start += rcv[si].len; si++; }
+            if (si >= rcv.size()) { // nothing received for this codeword: all soft bits "not sent"
+                d.llr_off0 = 0; d.len0 = 0; d.llr_off1 = 0xFFFFFFFFu;
+            } else {
+                const long in_seg = rcv_idx - seg_start;
+                const long avail0 = rcv[si].len - in_seg;
+                if (rcv[si].off == 0xFFFFFFFFu) { d.llr_off0 = 0; d.len0 = 0; d.llr_off1 = 0xFFFFFFFFu; }
+                else {
+                    d.llr_off0 = uint32_t(rcv[si].off + in_seg);
+                    if (avail0 >= want) { d.len0 = uint16_t(want); d.llr_off1 = 0xFFFFFFFFu; }
+                    else {
+                        d.len0 = uint16_t(avail0);
+                        d.llr_off1 = (si + 1 < rcv.size()) ? rcv[si + 1].off : 0xFFFFFFFFu;
+                    }
+                }
+            }
+            tb.cws.push_back(d);
+            rcv_idx += ncheck + k_;
+            d_idx += uint32_t(std::max(k_, 0));
+        }
+        done.push_back(std::move(tb));
+    }
+};
+
+} // namespace
+
+// ------------------------------------------------------------------ Receiver
+
+Receiver::~Receiver() = default;
+
+int Receiver::init()
+{
+    const int N = cfg.fft_len;
+    if (N < 64 || N > 1024 || (N & (N - 1))) { set_last_error("fft_len must be a power of two in [64,1024]"); return DTL_ERR_INVALID_ARG; }
+    if (cfg.cp_len < 0 || cfg.cp_len > N) { set_last_error("bad cp_len"); return DTL_ERR_INVALID_ARG; }
+    if (cfg.frame_length < 1) { set_last_error("bad frame_length"); return DTL_ERR_INVALID_ARG; }
+    if (cfg.occupied_carriers.empty() || cfg.occupied_carriers[0].empty()) { set_last_error("occupied_carriers empty"); return DTL_ERR_INVALID_ARG; }
+    if (int(cfg.sync_word1.size()) != N || int(cfg.sync_word2.size()) != N) {
+        set_last_error("Length of sync sequence(s) must be FFT length."); // ofdm_receiver.py:52-54
+        return DTL_ERR_INVALID_ARG;
+    }
+    for (auto& set : cfg.occupied_carriers)
+        for (int c : set) {
+            int idx = c < 0 ? c + N : c;
+            if (idx < 0 || idx >= N) { set_last_error("data carrier index out of bounds"); return DTL_ERR_INVALID_ARG; }
+        }
+    const size_t np = cfg.pilot_carriers.empty() ? 0 : cfg.pilot_carriers[0].size();
+    for (auto& set : cfg.pilot_carriers)
+        if (set.size() != np) { set_last_error("pilot carrier sets must have equal size"); return DTL_ERR_INVALID_ARG; }
+    for (auto& set : cfg.pilot_symbols)
+        if (set.size() != np) { set_last_error("pilot symbol sets must match the pilot carriers"); return DTL_ERR_INVALID_ARG; }
+    if (!cfg.pilot_carriers.empty() && cfg.pilot_symbols.empty()) { set_last_error("pilot_symbols empty"); return DTL_ERR_INVALID_ARG; }
+    capacity_ = 0;
+    for (int i = 0; i < cfg.frame_length; i++) capacity_ += int(cfg.occupied_carriers[i % cfg.occupied_carriers.size()].size());
+    decoders_.clear();
+    decoders_.push_back(nullptr); // index 0: "no FEC" (ldpc_dec.cc:25)
+    for (auto& text : cfg.alist_texts) {
+        auto dec = std::make_unique<LdpcDecoder>();
+        std::string err = dec->code.parse_alist(text);
+        if (!err.empty()) { set_last_error(err); return DTL_ERR_INVALID_ARG; }
+        dec->code.reduce();
+        dec->code.build_schedules();
+        dec->max_iterations = cfg.max_iterations > 0 ? cfg.max_iterations : 15;
+        if (cfg.bp_sigma > 0) dec->sigma = cfg.bp_sigma;
+        decoders_.push_back(std::move(dec));
+    }
+    if (cfg.has_fec && decoders_.size() < 2) { set_last_error("Misconfiguration: decoder not found!"); return DTL_ERR_INVALID_ARG; }
+    if (cfg.mcs.empty()) cfg.mcs = { { DBL_MIN, 1, 0 }, { 13, 2, 0 }, { 18, 3, 0 }, { 23, 4, 0 } }; // config.py:43-44
+    return DTL_OK;
+}
+
+int Receiver::upload_tables()
+{
+    const int N = cfg.fft_len;
+    const int h = cfg.header_len();
+    auto shifted = [&](int c) { int idx = c < 0 ? c + N : c; return (idx + N / 2) % N; };
+    std::vector<uint8_t> blob;
+    auto put = [&](const void* p, size_t bytes) {
+        size_t off = (blob.size() + 15) & ~size_t(15);
+        blob.resize(off + bytes);
+        if (bytes) std::memcpy(blob.data() + off, p, bytes);
+        return off;
+    };
+    std::vector<cf32> tw(N / 2);
+    for (int k = 0; k < N / 2; k++) {
+        const double ang = -2.0 * M_PI * k / N;
+        tw[k] = { float(std::cos(ang)), float(std::sin(ang)) };
+    }
+    std::vector<uint16_t> br(N);
+    int logn = 0;
+    while ((1 << logn) < N) logn++;
+    for (int i = 0; i < N; i++) {
+        int r = 0;
+        for (int b = 0; b < logn; b++) if (i & (1 << b)) r |= 1 << (logn - 1 - b);
+        br[i] = uint16_t(r);
+    }
+    const int n_occ_sets = int(cfg.occupied_carriers.size());
+    int max_occ = 0;
+    for (auto& s : cfg.occupied_carriers) max_occ = std::max<int>(max_occ, int(s.size()));
+    std::vector<int16_t> occ_idx(size_t(n_occ_sets) * max_occ, 0), occ_len(n_occ_sets);
+    std::vector<uint8_t> occupied(N, 0);
+    for (int s = 0; s < n_occ_sets; s++) {
+        occ_len[s] = int16_t(cfg.occupied_carriers[s].size());
+        for (size_t k = 0; k < cfg.occupied_carriers[s].size(); k++) {
+            const int idx = shifted(cfg.occupied_carriers[s][k]);
+            occ_idx[size_t(s) * max_occ + k] = int16_t(idx);
+            occupied[idx] = 1;
+        }
+    }
+    const int n_pilot_sets = int(cfg.pilot_carriers.size());
+    const int n_pilots = n_pilot_sets ? int(cfg.pilot_carriers[0].size()) : 0;
+    const int n_psym = std::max<int>(1, int(cfg.pilot_symbols.size()));
+    std::vector<uint8_t> pmask(size_t(std::max(n_pilot_sets, 1)) * N, 0);
+    std::vector<cf32> pval(size_t(n_psym) * N, cf32{ 0, 0 });
+    for (int s = 0; s < n_pilot_sets; s++)
+        for (int k = 0; k < n_pilots; k++) pmask[size_t(s) * N + shifted(cfg.pilot_carriers[s][k])] = 1;
+    for (size_t s = 0; s < cfg.pilot_symbols.size(); s++) { // equalizer.cc:196-214: all symbol sets are loaded
+        const int cset = int(s % std::max(n_pilot_sets, 1));
+        for (int k = 0; k < n_pilots; k++) pval[s * N + shifted(cfg.pilot_carriers[cset][k])] = cfg.pilot_symbols[s][k];
+    }
+    // ofdm_chanest_vcvc ctor
+    std::vector<cf32> corr(N), ref(cfg.sync_word2);
+    int first_active = 0, last_active = N - 1;
+    for (int i = 0; i < N; i++) if (ref[i].re != 0 || ref[i].im != 0) { first_active = i; break; }
+    for (int i = N - 1; i >= 0; i--) if (ref[i].re != 0 || ref[i].im != 0) { last_active = i; break; }
+    int gmin = -first_active, gmax = N - last_active - 1;
+    if (gmin % 2) gmin++;
+    if (gmax % 2) gmax--;
+    for (int i = 0; i < N; i++) {
+        const cf32 s1 = cfg.sync_word1[i], s2 = cfg.sync_word2[i];
+        if (s1.re == 0 && s1.im == 0) corr[i] = { 0, 0 };
+        else { // complex division, Smith's form (what std::complex<float> /= does through libgcc)
+            const float a = s2.re, b = s2.im, c = s1.re, d = s1.im;
+            if (std::fabs(c) < std::fabs(d)) { float r = c / d, den = (c * r) + d; corr[i] = { ((a * r) + b) / den, ((b * r) - a) / den }; }
+            else { float r = d / c, den = (d * r) + c; corr[i] = { ((b * r) + a) / den, (b - (a * r)) / den }; }
+        }
+    }
+    // constellation tables (gr::digital constellation_{bpsk,qpsk,8psk,16qam}; dtl QPSK x0.5)
+    std::vector<cf32> pts(5 * 16, cf32{ 0, 0 });
+    pts[1 * 16 + 0] = { -1, 0 }; pts[1 * 16 + 1] = { 1, 0 };
+    {
+        const float s = float(double(float(0.707107)) * 0.5); // SQRT_TWO macro, lib/dtl/constellation.cc:19-23
+        pts[2 * 16 + 0] = { -s, -s }; pts[2 * 16 + 1] = { s, -s }; pts[2 * 16 + 2] = { -s, s }; pts[2 * 16 + 3] = { s, s };
+    }
+    {
+        const float angle = float(M_PI / 8.0);
+        const int mult[8] = { 1, 7, 15, 9, 3, 5, 13, 11 };
+        for (int i = 0; i < 8; i++) pts[3 * 16 + i] = { float(std::cos(mult[i] * angle)), float(std::sin(mult[i] * angle)) };
+    }
+    {
+        const float level = std::sqrt(float(0.1));
+        for (int i = 0; i < 16; i++)
+            pts[4 * 16 + i] = { ((i & 2) ? 3 : 1) * level * ((i & 4) ? -1.f : 1.f), ((i & 1) ? 3 : 1) * level * ((i & 8) ? 1.f : -1.f) };
+    }
+    const size_t o_tw = put(tw.data(), tw.size() * sizeof(cf32));
+    const size_t o_br = put(br.data(), br.size() * 2);
+    const size_t o_oi = put(occ_idx.data(), occ_idx.size() * 2);
+    const size_t o_ol = put(occ_len.data(), occ_len.size() * 2);
+    const size_t o_oc = put(occupied.data(), occupied.size());
+    const size_t o_pm = put(pmask.data(), pmask.size());
+    const size_t o_pv = put(pval.data(), pval.size() * sizeof(cf32));
+    const size_t o_cv = put(corr.data(), corr.size() * sizeof(cf32));
+    const size_t o_rf = put(ref.data(), ref.size() * sizeof(cf32));
+    const size_t o_pt = put(pts.data(), pts.size() * sizeof(cf32));
+    int rc = tab_blob_.ensure(blob.size());
+    if (rc != DTL_OK) return rc;
+    DTL_HIP_CHECK(hipMemcpy(tab_blob_.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    auto* b = static_cast<uint8_t*>(tab_blob_.p);
+    tab_.fft_len = N; tab_.cp_len = cfg.cp_len; tab_.frame_length = cfg.frame_length; tab_.header_len = h;
+    tab_.has_fec = cfg.has_fec ? 1 : 0;
+    tab_.n_occ_sets = n_occ_sets; tab_.max_occ = max_occ; tab_.n_pilot_sets = n_pilot_sets; tab_.n_pilots = n_pilots;
+    tab_.n_pilot_sym_sets = n_psym; tab_.frame_capacity = capacity_;
+    tab_.hdr_bits = 0;
+    for (int i = 0; i < h; i++) tab_.hdr_bits += occ_len[i % n_occ_sets];
+    tab_.g_min = gmin; tab_.g_max = gmax;
+    tab_.eq_alpha = cfg.eq_alpha; tab_.llr_dist_mode = cfg.llr_dist_mode;
+    tab_.twiddle = reinterpret_cast<const cf32*>(b + o_tw);
+    tab_.bitrev = reinterpret_cast<const uint16_t*>(b + o_br);
+    tab_.occ_idx = reinterpret_cast<const int16_t*>(b + o_oi);
+    tab_.occ_len = reinterpret_cast<const int16_t*>(b + o_ol);
+    tab_.occupied = b + o_oc;
+    tab_.pilot_mask = b + o_pm;
+    tab_.pilot_val = reinterpret_cast<const cf32*>(b + o_pv);
+    tab_.corr_v = reinterpret_cast<const cf32*>(b + o_cv);
+    tab_.ref_sym = reinterpret_cast<const cf32*>(b + o_rf);
+    tab_.cnst_pts = reinterpret_cast<const cf32*>(b + o_pt);
+    for (auto& d : decoders_)
+        if (d && !d->uploaded()) { rc = d->upload(); if (rc != DTL_OK) return rc; }
+    uploaded_ = true;
+    return DTL_OK;
+}
+
+#define DTL_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != DTL_OK) return _rc; \
+    } while (0)
+
+int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t st)
+{
+    if (!d_iq || n < 0) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
+    if (n > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
+    if (!uploaded_) DTL_TRY(upload_tables());
+    const int N = cfg.fft_len, cp = cfg.cp_len, P = N + cp, h = cfg.header_len(), L = cfg.frame_length;
+    const int hdr_syms = 2 + h;
+    frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
+    n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
+    double t0 = now_ms();
+
+    // ---- K1: timing metric -> threshold crossings -> plateau detector (host)
+    const unsigned max_edges = unsigned(std::min<int64_t>(std::max<int64_t>(n / 8, 1024), 1 << 26));
+    DTL_TRY(d_edges_.ensure(size_t(max_edges) * 8));
+    DTL_TRY(d_counter_.ensure(16));
+    DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 16, st));
+    float* metric = nullptr;
+    if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
+    DTL_TRY(launch_sync_edges(d_iq, n, N, cfg.sync_threshold, d_edges_.as<unsigned long long>(),
+                              d_counter_.as<unsigned int>(), max_edges, metric, st));
+    unsigned n_edges = 0;
+    DTL_HIP_CHECK(hipMemcpyAsync(&n_edges, d_counter_.p, 4, hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    if (n_edges > max_edges) { set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
+    std::vector<unsigned long long> edges(n_edges);
+    if (n_edges) DTL_HIP_CHECK(hipMemcpy(edges.data(), d_edges_.p, size_t(n_edges) * 8, hipMemcpyDeviceToHost));
+    raw_triggers = plateau_from_edges(std::move(edges), n, cp);
+    stage_ms[0] = now_ms() - t0; t0 = now_ms();
+
+    // ---- K1b: arg(P) at the raw triggers; oscillator segments (sample_and_hold + frequency_modulator_fc)
+    const int n_raw = int(raw_triggers.size());
+    trigger_angles.assign(n_raw, 0.0f);
+    if (n_raw) {
+        DTL_TRY(d_trig_.ensure(size_t(n_raw) * 8));
+        DTL_TRY(d_angle_.ensure(size_t(n_raw) * 4));
+        DTL_HIP_CHECK(hipMemcpyAsync(d_trig_.p, raw_triggers.data(), size_t(n_raw) * 8, hipMemcpyHostToDevice, st));
+        DTL_TRY(launch_trigger_angle(d_iq, n, N, d_trig_.as<int64_t>(), n_raw, d_angle_.as<float>(), st));
+        DTL_HIP_CHECK(hipMemcpyAsync(trigger_angles.data(), d_angle_.p, size_t(n_raw) * 4, hipMemcpyDeviceToHost, st));
+        DTL_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    std::vector<CfoSegment> segs(n_raw);
+    {
+        const float sens = float(-2.0 / N);
+        double phase = 0.0; // oscillator phase before the first trigger: held angle 0 => phase stays 0
+        for (int j = 0; j < n_raw; j++) {
+            segs[j].start = raw_triggers[j];
+            segs[j].angle = trigger_angles[j];
+            segs[j].phase0 = phase;
+            segs[j].pad = 0;
+            const int64_t next = (j + 1 < n_raw) ? raw_triggers[j + 1] : n;
+            phase = phase + double(sens * trigger_angles[j]) * double(next - raw_triggers[j]);
+            phase = std::fmod(phase + M_PI, 2.0 * M_PI);
+            if (phase < 0) phase += 2.0 * M_PI;
+            phase -= M_PI;
+        }
+    }
+    // ---- frame_detect_bb (optional) -> candidates for phase A
+    if (cfg.use_sync_correct) {
+        FrameDetectState fds;
+        fds.frame_len = (L + hdr_syms) * P; // ofdm_receiver.py:77-78
+        fixed_triggers = fix_sync_sparse(fds, raw_triggers, n);
+    } else {
+        fixed_triggers = raw_triggers;
+    }
+    std::vector<Candidate> cands;
+    for (int64_t tpos : fixed_triggers) {
+        if (tpos + int64_t(hdr_syms) * P > n) break;
+        Candidate c{};
+        c.trigger = tpos;
+        c.seg = int(std::upper_bound(raw_triggers.begin(), raw_triggers.end(), tpos) - raw_triggers.begin()) - 1;
+        cands.push_back(c);
+    }
+    const int n_cand = int(cands.size());
+    stage_ms[1] = now_ms() - t0; t0 = now_ms();
+
+    // ---- phase A: header kernel
+    std::vector<HeaderRec> recs(n_cand);
+    if (n_cand) {
+        DTL_TRY(d_cands_.ensure(size_t(n_cand) * sizeof(Candidate)));
+        DTL_TRY(d_segs_.ensure(std::max<size_t>(1, segs.size()) * sizeof(CfoSegment)));
+        DTL_TRY(d_recs_.ensure(size_t(n_cand) * sizeof(HeaderRec)));
+        DTL_TRY(d_taps.ensure(size_t(n_cand) * N * sizeof(cf32)));
+        uint8_t* hb = nullptr;
+        if (flags & RX_WANT_HDR_BITS) { DTL_TRY(d_hdr_bits.ensure(size_t(n_cand) * tab_.hdr_bits)); hb = d_hdr_bits.as<uint8_t>(); }
+        DTL_HIP_CHECK(hipMemcpyAsync(d_cands_.p, cands.data(), size_t(n_cand) * sizeof(Candidate), hipMemcpyHostToDevice, st));
+        if (!segs.empty())
+            DTL_HIP_CHECK(hipMemcpyAsync(d_segs_.p, segs.data(), segs.size() * sizeof(CfoSegment), hipMemcpyHostToDevice, st));
+        DTL_TRY(launch_header(tab_, d_iq, n, d_cands_.as<Candidate>(), n_cand, d_segs_.as<CfoSegment>(), n_raw,
+                              d_recs_.as<HeaderRec>(), d_taps.as<cf32>(), hb, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(recs.data(), d_recs_.p, size_t(n_cand) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
+        DTL_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    stage_ms[2] = now_ms() - t0; t0 = now_ms();
+
+    // ---- header_payload_demux walk + header_parser state
+    std::vector<FrameDesc> fdesc;
+    std::vector<uint32_t> llr_off;
+    int state_cnst = 4; // d_constellation(QAM16), packet_header.cc:70
+    {
+        int64_t pos = 0;
+        for (int ci = 0; ci < n_cand; ci++) {
+            const int64_t trig = cands[ci].trigger;
+            if (trig < pos) continue; // consumed by a previous frame
+            const HeaderRec& r = recs[ci];
+            FrameInfo fi{};
+            fi.trigger = trig; fi.header_ok = r.crc_ok; fi.carr_offset = r.carr_offset; fi.payload_index = -1; fi.cand = ci;
+            fi.llr_offset = -1;
+            if (!r.crc_ok) { frames.push_back(fi); pos = trig + 1; continue; }
+            if (trig + int64_t(hdr_syms + L) * P > n) break;
+            if (r.cnst && r.cnst <= 4) state_cnst = r.cnst; // :269-273
+            const int bps = bits_per_symbol(state_cnst);
+            int n_syms = r.payload_len * 8 / bps;
+            if (r.payload_len * 8 % bps) n_syms++;
+            fi.payload_len = r.payload_len; fi.frame_no = r.frame_no; fi.cnst = state_cnst; fi.fb_cnst = r.fb_cnst;
+            fi.tb_no = r.tb_no; fi.fec_fb = r.fec_fb; fi.tb_offset = r.tb_offset; fi.fec = r.fec; fi.tb_payload = r.tb_payload;
+            fi.n_payload_syms = n_syms;
+            fi.payload_index = int(fdesc.size());
+            FrameDesc d{};
+            d.trigger = trig; d.seg = cands[ci].seg; d.cand = ci; d.cnst = state_cnst; d.carr_offset = r.carr_offset;
+            // ofdm_serializer_vcc truncation to packet_length; payload == 0 frames are dropped (:218,254)
+            d.n_syms = r.payload_len ? std::min(n_syms, capacity_) : 0;
+            fdesc.push_back(d);
+            frames.push_back(fi);
+            pos = trig + int64_t(hdr_syms + L) * P;
+        }
+    }
+    const int n_frames = int(fdesc.size());
+    n_payload_frames = n_frames;
+
+    // ---- soft-bit stream layout + transport-block gather tables (tb_decoder::process_frame)
+    llr_off.assign(n_frames, 0);
+    uint64_t llr_total = 0;
+    for (int f = 0; f < n_frames; f++) {
+        llr_off[f] = uint32_t(llr_total);
+        llr_total += uint64_t(fdesc[f].n_syms) * bits_per_symbol(fdesc[f].cnst);
+    }
+    if (llr_total + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
+    n_llr = int64_t(llr_total);
+    {
+        size_t fidx = 0;
+        for (auto& fi : frames) if (fi.payload_index >= 0) { fi.llr_offset = llr_off[fidx]; fidx++; }
+    }
+    TbAssembler asmb;
+    if (cfg.has_fec) {
+        int max_n = 0, max_bps = 0;
+        for (auto& d : decoders_) if (d) max_n = std::max(max_n, d->code.n);
+        for (auto& m : cfg.mcs) max_bps = std::max(max_bps, m.cnst); // python/dtl/ofdm_adaptive.py:8
+        asmb.rcv_cap = 2L * max_n * compute_tb_len(max_n, capacity_ * max_bps); // tb_decoder.cc:24-27
+        size_t fidx = 0;
+        for (auto& fi : frames) {
+            if (fi.payload_index < 0) continue;
+            const FrameDesc& d = fdesc[fidx];
+            const uint32_t base = llr_off[fidx];
+            fidx++;
+            if (fi.payload_len == 0) continue; // empty frame never reaches the FEC decoder
+            const int bps = bits_per_symbol(d.cnst);
+            const long in_len = long(d.n_syms) * bps;
+            if (fi.fec <= 0 || fi.fec >= int(decoders_.size())) continue; // reference dereferences a null decoder here
+            const LdpcCode& code = decoders_[fi.fec]->code;
+            const int n_ = code.n, k_ = code.k, ncheck = n_ - k_;
+            const long frame_payload = 8L * fi.payload_len;           // fec_utils.cc:93
+            const long tb_offset = 8L * fi.tb_offset;                 // fec_decoder_impl.cc:147
+            const int frame_len = 8 * align_bits_to_bytes(capacity_ * bps); // :207
+            auto info_nk = [&](int& nn, int& kk) { const LdpcCode& c = decoders_[asmb.info_code]->code; nn = c.n; kk = c.k; };
+            if (fi.tb_no == asmb.tb_number) {
+                if (asmb.buf_idx + frame_payload > asmb.rcv_cap) { set_last_error("rcv buffer does not have enough capacity!"); return DTL_ERR_CAPACITY; }
+                asmb.append(base, 0, frame_payload, in_len);
+                asmb.buf_idx += frame_payload;
+                const int ncws = compute_tb_len(n_, frame_len);
+                if (asmb.rcv_size >= long(ncheck) * ncws + fi.tb_payload) {
+                    int nn, kk; info_nk(nn, kk);
+                    asmb.decode(ncws, nn, kk, fi.tb_no, fi.tb_payload);
+                    asmb.buf_idx = 0; asmb.clear();
+                }
+            } else if (asmb.rcv_size == 0 && tb_offset == frame_payload) {
+                asmb.have_info = true; asmb.info_tb_payload = fi.tb_payload; asmb.info_code = fi.fec;
+                asmb.tb_number = fi.tb_no; asmb.buf_idx = 0; asmb.clear();
+                asmb.append(base, 0, tb_offset, in_len);
+                asmb.decode(compute_tb_len(n_, frame_len), n_, k_, fi.tb_no, fi.tb_payload);
+                asmb.clear();
+            } else {
+                if (tb_offset > 0) asmb.append(base, 0, tb_offset, in_len);
+                if (asmb.rcv_size > 0 && asmb.have_info) {
+                    int nn, kk; info_nk(nn, kk);
+                    asmb.decode(compute_tb_len(nn, frame_len), nn, kk, asmb.tb_number, asmb.info_tb_payload);
+                }
+                asmb.have_info = true; asmb.info_tb_payload = fi.tb_payload; asmb.info_code = fi.fec;
+                asmb.tb_number = fi.tb_no; asmb.buf_idx = 0; asmb.clear();
+                int extra_bits = 0;
+                if (tb_offset % bps) extra_bits = int(bps - tb_offset % bps);
+                const long new_tb_offset = tb_offset ? tb_offset + extra_bits : 0;
+                asmb.append(base, new_tb_offset, frame_payload + extra_bits, in_len);
+                asmb.buf_idx += frame_payload - tb_offset;
+                const int tb_len = compute_tb_len(n_, frame_len);
+                const long tb_size = 8L * align_bits_to_bytes(tb_len * ncheck + fi.tb_payload);
+                if (frame_payload - tb_offset == tb_size) {
+                    asmb.decode(tb_len, n_, k_, fi.tb_no, fi.tb_payload);
+                    asmb.buf_idx = 0; asmb.clear();
+                }
+            }
+        }
+    }
+    // order the codewords: grouped per LDPC code, TB order inside a group
+    const int n_tbs = int(asmb.done.size());
+    std::vector<CwDesc> cw_all;
+    std::vector<TbDesc> tb_desc(n_tbs);
+    std::vector<std::pair<int, std::pair<size_t, size_t>>> code_ranges; // code -> [first, count) in cw_all
+    {
+        uint32_t bits_base = 0;
+        std::vector<uint32_t> tb_bits_off(n_tbs);
+        for (int tix = 0; tix < n_tbs; tix++) { tb_bits_off[tix] = bits_base; bits_base += asmb.done[tix].n_bits + 8; }
+        for (int code = 1; code < int(decoders_.size()); code++) {
+            const size_t first = cw_all.size();
+            for (int tix = 0; tix < n_tbs; tix++) {
+                auto& tb = asmb.done[tix];
+                if (tb.code != code) continue;
+                tb_desc[tix] = { tb_bits_off[tix], tb.n_bits, uint32_t(cw_all.size()), uint32_t(tb.cws.size()) };
+                for (auto d : tb.cws) { d.out_off += tb_bits_off[tix]; cw_all.push_back(d); }
+            }
+            if (cw_all.size() > first) code_ranges.push_back({ code, { first, cw_all.size() - first } });
+        }
+        n_codewords = int64_t(cw_all.size());
+        DTL_TRY(d_cw_bits.ensure(size_t(bits_base) + 4096));
+    }
+    stage_ms[3] = now_ms() - t0; t0 = now_ms();
+
+    // ---- phase B: payload kernel -> LDPC -> TB check -> compaction
+    std::vector<FrameStat> stats(n_frames);
+    std::vector<TbResult> tb_res(n_tbs);
+    std::vector<int32_t> nofec_info(size_t(n_frames) * 2, 0);
+    uint32_t total_bytes = 0;
+    const int nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
+    if (n_frames) {
+        DTL_TRY(d_frames_.ensure(size_t(n_frames) * sizeof(FrameDesc)));
+        DTL_TRY(d_stats_.ensure(size_t(n_frames) * sizeof(FrameStat)));
+        DTL_TRY(d_llr_off_.ensure(size_t(n_frames) * 4));
+        DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
+        cf32 *eh = nullptr, *es = nullptr, *ss = nullptr;
+        if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_frames) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
+        if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_frames) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
+        if (flags & RX_WANT_SOFT_SYMS) {
+            DTL_TRY(d_soft_syms.ensure(size_t(n_frames) * capacity_ * sizeof(cf32)));
+            DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_frames) * capacity_ * sizeof(cf32), st));
+            ss = d_soft_syms.as<cf32>();
+        }
+        uint8_t* nofec_bytes = nullptr;
+        int32_t* nofec_inf = nullptr;
+        if (!cfg.has_fec) {
+            DTL_TRY(d_staging_.ensure(size_t(n_frames) * nofec_stride));
+            DTL_TRY(d_nofec_info_.ensure(size_t(n_frames) * 8));
+            DTL_HIP_CHECK(hipMemsetAsync(d_nofec_info_.p, 0, size_t(n_frames) * 8, st));
+            nofec_bytes = d_staging_.as<uint8_t>();
+            nofec_inf = d_nofec_info_.as<int32_t>();
+        }
+        DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.p, fdesc.data(), size_t(n_frames) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.p, llr_off.data(), size_t(n_frames) * 4, hipMemcpyHostToDevice, st));
+        DTL_TRY(launch_payload(tab_, d_iq, n, d_frames_.as<FrameDesc>(), n_frames, d_segs_.as<CfoSegment>(), n_raw,
+                               d_taps.as<cf32>(), d_stats_.as<FrameStat>(), d_llr_off_.as<uint32_t>(),
+                               d_llr.as<float>(), eh, es, ss, nofec_bytes, nofec_inf, nofec_stride, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(stats.data(), d_stats_.p, size_t(n_frames) * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
+    }
+    DTL_TRY(d_total_.ensure(16));
+    if (cfg.has_fec) {
+        int stride = 16;
+        for (auto& tb : asmb.done) stride = std::max<int>(stride, int(tb.n_bits / 8) + 8);
+        stride = (stride + 15) & ~15;
+        if (n_tbs) {
+            DTL_TRY(d_cwdesc_.ensure(cw_all.size() * sizeof(CwDesc)));
+            DTL_TRY(d_cw_nit.ensure(cw_all.size() * 4));
+            DTL_TRY(d_tbdesc_.ensure(size_t(n_tbs) * sizeof(TbDesc)));
+            DTL_TRY(d_tbres_.ensure(size_t(n_tbs) * sizeof(TbResult)));
+            DTL_TRY(d_len_.ensure(size_t(n_tbs) * 4));
+            DTL_TRY(d_offs_.ensure(size_t(n_tbs) * 4));
+            DTL_TRY(d_staging_.ensure(size_t(n_tbs) * stride));
+            DTL_HIP_CHECK(hipMemcpyAsync(d_cwdesc_.p, cw_all.data(), cw_all.size() * sizeof(CwDesc), hipMemcpyHostToDevice, st));
+            DTL_HIP_CHECK(hipMemcpyAsync(d_tbdesc_.p, tb_desc.data(), size_t(n_tbs) * sizeof(TbDesc), hipMemcpyHostToDevice, st));
+            for (auto& cr : code_ranges)
+                DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
+                                                    d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st));
+            DTL_TRY(launch_tb_check(d_tbdesc_.as<TbDesc>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
+                                    d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st));
+            uint64_t max_out = 0;
+            for (auto& tb : asmb.done) max_out += tb.n_bits / 8;
+            DTL_TRY(d_payload.ensure(max_out + 64));
+            DTL_TRY(launch_compact(d_staging_.as<uint8_t>(), stride, d_len_.as<int32_t>(), n_tbs, d_offs_.as<uint32_t>(),
+                                   d_total_.as<uint32_t>(), d_payload.as<uint8_t>(), st));
+            DTL_HIP_CHECK(hipMemcpyAsync(tb_res.data(), d_tbres_.p, size_t(n_tbs) * sizeof(TbResult), hipMemcpyDeviceToHost, st));
+            DTL_HIP_CHECK(hipMemcpyAsync(&total_bytes, d_total_.p, 4, hipMemcpyDeviceToHost, st));
+        }
+    } else if (n_frames) {
+        DTL_TRY(d_len_.ensure(size_t(n_frames) * 4));
+        DTL_TRY(d_offs_.ensure(size_t(n_frames) * 4));
+        DTL_TRY(d_payload.ensure(size_t(n_frames) * nofec_stride + 64));
+        DTL_TRY(launch_nofec_lengths(d_nofec_info_.as<int32_t>(), n_frames, d_len_.as<int32_t>(), st));
+        DTL_TRY(launch_compact(d_staging_.as<uint8_t>(), nofec_stride, d_len_.as<int32_t>(), n_frames, d_offs_.as<uint32_t>(),
+                               d_total_.as<uint32_t>(), d_payload.as<uint8_t>(), st));
+        DTL_HIP_CHECK(hipMemcpyAsync(nofec_info.data(), d_nofec_info_.p, size_t(n_frames) * 8, hipMemcpyDeviceToHost, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(&total_bytes, d_total_.p, 4, hipMemcpyDeviceToHost, st));
+    }
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    n_payload_bytes = total_bytes;
+    stage_ms[4] = now_ms() - t0; t0 = now_ms();
+
+    // ---- per-frame sequential bookkeeping: lost frames (:124-138), feedback decision
+    {
+        FeedbackDecision fb;
+        fb.init(cfg.mcs, cfg.hysteresis, cfg.decision_th, cfg.initial_mcs);
+        int expected_frame_no = 0;
+        long lost_total = 0;
+        size_t fidx = 0;
+        for (auto& fi : frames) {
+            if (fi.payload_index < 0) continue;
+            const FrameStat& s = stats[fidx++];
+            int lost = 0;
+            if (fi.frame_no != expected_frame_no)
+                lost = fi.frame_no < expected_frame_no ? 4096 + fi.frame_no - expected_frame_no : fi.frame_no - expected_frame_no;
+            lost_total += lost;
+            expected_frame_no = (fi.frame_no + 1) % 4096;
+            fi.snr_db = s.snr_db; fi.noise = s.noise_lin;
+            fb.get(s.snr_db, &fi.feedback_cnst, &fi.feedback_fec);
+            fi.lost_frames = int(lost_total);
+        }
+    }
+    // ---- TB records
+    if (cfg.has_fec) {
+        int64_t out_off = 0;
+        for (int tix = 0; tix < n_tbs; tix++) {
+            TbInfo ti{};
+            ti.tb_no = asmb.done[tix].tb_no; ti.tb_payload = asmb.done[tix].tb_payload;
+            ti.crc_ok = tb_res[tix].crc_ok; ti.avg_it = tb_res[tix].avg_it; ti.user_bits = tb_res[tix].user_bits;
+            ti.out_offset = ti.crc_ok ? out_off : -1;
+            if (ti.crc_ok) out_off += ti.user_bits / 8;
+            tbs.push_back(ti);
+        }
+    } else {
+        int64_t out_off = 0;
+        size_t fidx = 0;
+        for (auto& fi : frames) {
+            if (fi.payload_index < 0) continue;
+            const size_t f = fidx++;
+            if (fi.payload_len == 0) continue;
+            TbInfo ti{};
+            const int nw = nofec_info[2 * f + 1];
+            ti.tb_no = fi.frame_no; ti.tb_payload = nw; ti.crc_ok = nofec_info[2 * f]; ti.avg_it = 0;
+            ti.user_bits = (nw - 4) * 8; ti.out_offset = out_off;
+            if (nw >= 4) out_off += nw - 4;
+            tbs.push_back(ti);
+        }
+    }
+    stage_ms[5] = now_ms() - t0;
+    return DTL_OK;
+}
+
+} // namespace dtl

@@ -1,0 +1,128 @@
+// rx_pipeline.h -- host side of the batched receive pipeline: configuration, device tables, the
+// sequential control logic the reference keeps in single-threaded blocks (plateau detector,
+// frame_detect_bb, header/payload demux, header-parser state, transport-block reassembly,
+// feedback decision) and the kernel orchestration.
+#pragma once
+
+#include "dtl_common.h"
+#include "ldpc_bp.h"
+#include "rx_types.h"
+
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace dtl {
+
+struct McsEntry {
+    double snr_th;
+    int cnst;
+    int fec;
+};
+
+struct RxConfig {
+    int fft_len = 64, cp_len = 16, frame_length = 20;
+    bool has_fec = false;
+    std::vector<std::vector<int>> occupied_carriers;
+    std::vector<std::vector<int>> pilot_carriers;
+    std::vector<std::vector<cf32>> pilot_symbols;
+    std::vector<cf32> sync_word1, sync_word2;
+    float sync_threshold = 0.95f;
+    float eq_alpha = 0.1f;
+    bool use_sync_correct = true;
+    bool scramble_header = false;
+    int llr_dist_mode = 0;
+    int max_iterations = 15;
+    float bp_sigma = 0.0f; // 0 => sqrt(2)
+    std::vector<std::string> alist_texts; // fec_codes, index i -> FEC id i+1
+    std::vector<McsEntry> mcs;
+    int initial_mcs = 0;
+    double hysteresis = 1.0;  // ofdm_receiver.py:167 ofdm_adaptive_feedback_decision(1, 5, ...)
+    int decision_th = 5;
+    int header_len() const { return has_fec ? 2 : 1; } // ofdm_receiver.py:66-68
+};
+
+// lib/dtl/ofdm_adaptive_frame_detect_bb_impl.cc state (d_* members)
+struct FrameDetectState {
+    int frame_len = 0, remainder = 0;
+    long missing_count = 0, correction_count = 0, error_count = 0;
+    int acc_error = 0, trigger_counter = 0, synced = 0;
+    bool in_sync = false;
+};
+// sparse-trigger form of ofdm_adaptive_frame_detect_bb_impl::fix_sync (one buffer of `len` items)
+std::vector<int64_t> fix_sync_sparse(FrameDetectState& s, const std::vector<int64_t>& triggers, int64_t len);
+// plateau_detector_fb(max_len, threshold) from the metric's threshold crossings
+std::vector<int64_t> plateau_from_edges(std::vector<unsigned long long> edges, int64_t n, int max_len);
+
+// lib/dtl/ofdm_adaptive_feedback_decision.cc
+struct FeedbackDecision {
+    std::vector<McsEntry> lut;
+    double hysteresis = 1;
+    int decision_th = 5, counter = 0, last = 0, pending = 0;
+    void init(const std::vector<McsEntry>& mcs, double hyst, int th, int initial);
+    void get(double snr, int* cnst, int* fec);
+};
+
+struct FrameInfo { // mirrors dtl_rx_frame_info of the C ABI
+    int64_t trigger;
+    int32_t header_ok, carr_offset;
+    int32_t payload_len, frame_no, cnst, fb_cnst, tb_no, fec_fb, tb_offset, fec, tb_payload;
+    int32_t n_payload_syms, payload_index;
+    double snr_db, noise;
+    int32_t feedback_cnst, feedback_fec, lost_frames, cand;
+    int64_t llr_offset;
+};
+
+struct TbInfo { // mirrors dtl_rx_tb_info
+    int32_t tb_no, tb_payload, crc_ok, avg_it, user_bits, pad;
+    int64_t out_offset; // byte offset in the payload output, -1 when the CRC failed
+};
+
+enum ProcessFlags : unsigned {
+    RX_WANT_EQ_HARD = 1u, RX_WANT_EQ_SOFT = 2u, RX_WANT_SOFT_SYMS = 4u, RX_WANT_HDR_BITS = 8u,
+    RX_WANT_METRIC = 16u,
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf();
+    int ensure(size_t bytes);
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+class Receiver {
+public:
+    RxConfig cfg;
+    ~Receiver();
+    int init(); // validate, derive tables, parse codes (no GPU needed)
+    int process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t stream);
+
+    // results of the last process() call
+    std::vector<FrameInfo> frames;   // every trigger the demux visited, in order
+    std::vector<TbInfo> tbs;
+    std::vector<int64_t> raw_triggers, fixed_triggers;
+    std::vector<float> trigger_angles; // per raw trigger
+    int64_t n_payload_frames = 0;
+    int64_t n_payload_bytes = 0;
+    int64_t n_llr = 0;
+    int64_t n_codewords = 0;
+    double stage_ms[8] = { 0 };
+    DevBuf d_payload, d_eq_hard, d_eq_soft, d_soft_syms, d_llr, d_taps, d_hdr_bits, d_metric, d_cw_bits, d_cw_nit;
+
+    int frame_capacity() const { return capacity_; }
+    int frame_samples() const { return (2 + cfg.header_len() + cfg.frame_length) * (cfg.fft_len + cfg.cp_len); }
+    const std::vector<std::unique_ptr<LdpcDecoder>>& decoders() const { return decoders_; }
+
+private:
+    int upload_tables();
+    RxTables tab_{};
+    DevBuf tab_blob_;
+    bool uploaded_ = false;
+    int capacity_ = 0;
+    std::vector<std::unique_ptr<LdpcDecoder>> decoders_; // index 0 == nullptr ("no FEC")
+    DevBuf d_edges_, d_counter_, d_trig_, d_angle_, d_cands_, d_segs_, d_recs_, d_frames_, d_stats_, d_llr_off_,
+        d_cwdesc_, d_tbdesc_, d_tbres_, d_len_, d_offs_, d_total_, d_staging_, d_nofec_info_;
+};
+
+} // namespace dtl

@@ -1,0 +1,95 @@
+// rx_types.h -- data structures shared by the host pipeline and the HIP kernels of the
+// adaptive-OFDM receive path (python/dtl/ofdm_receiver.py:59-246 of the reference).
+#pragma once
+
+#include <cstdint>
+
+namespace dtl {
+
+struct cf32 {
+    float re, im;
+};
+
+constexpr int kMaxBps = 4;
+constexpr int kMaxHdrSyms = 4;
+
+// Read-only device tables derived from the configuration (one blob, see Receiver::upload_tables).
+struct RxTables {
+    int fft_len, cp_len, frame_length, header_len, has_fec;
+    int n_occ_sets, max_occ, n_pilot_sets, n_pilots, n_pilot_sym_sets;
+    int frame_capacity;        // QAM symbols per frame (python/dtl/ofdm_adaptive.py:1-6)
+    int hdr_bits;              // header_len * len(occupied_carriers[0])
+    int g_min, g_max;          // integer-CFO search range (even steps), ofdm_chanest_vcvc ctor
+    float eq_alpha;
+    int llr_dist_mode;
+    const cf32* twiddle;       // fft_len/2 : exp(-j 2 pi k / N)
+    const uint16_t* bitrev;    // fft_len
+    const int16_t* occ_idx;    // n_occ_sets x max_occ : shifted positions of the data carriers
+    const int16_t* occ_len;    // n_occ_sets
+    const uint8_t* occupied;   // fft_len : union of all data-carrier sets (shifted positions)
+    const uint8_t* pilot_mask; // n_pilot_sets x fft_len
+    const cf32* pilot_val;     // n_pilot_sym_sets x fft_len
+    const cf32* corr_v;        // fft_len : sync2 / sync1 on sync1's non-zero carriers
+    const cf32* ref_sym;       // fft_len : sync word 2
+    const cf32* cnst_pts;      // 5 x 16 constellation points (index = constellation_type_t)
+};
+
+// A stretch of the stream over which the fine-CFO oscillator runs at one held angle
+// (sample_and_hold_ff + frequency_modulator_fc, ofdm_receiver.py:75,89).
+struct CfoSegment {
+    int64_t start;   // first sample index at which `angle` is held
+    double phase0;   // oscillator phase just before `start`
+    float angle;     // arg(P) sampled at the trigger
+    int32_t pad;
+};
+
+// One Schmidl-Cox trigger handed to the header kernel (phase A).
+struct Candidate {
+    int64_t trigger;  // index in the (delayed) stream the demux cuts at
+    int32_t seg;      // index of the CfoSegment active at `trigger`
+    int32_t pad;
+};
+
+// Raw result of phase A for one candidate (header_parser fields before the sequential
+// "keep previous MCS" rule of lib/dtl/ofdm_adaptive_packet_header.cc:269-273).
+struct HeaderRec {
+    int32_t crc_ok;
+    int32_t carr_offset;
+    int32_t payload_len, frame_no, cnst, fb_cnst;
+    int32_t tb_no, fec_fb, tb_offset, fec, tb_payload;
+    int32_t pad;
+};
+
+// One accepted frame handed to the payload kernel (phase B).
+struct FrameDesc {
+    int64_t trigger;
+    int32_t seg;
+    int32_t cand;          // candidate index (taps are stored per candidate)
+    int32_t cnst;          // constellation_type_t of the payload
+    int32_t carr_offset;
+    int32_t n_syms;        // packet_length tag: QAM symbols carried (0 => empty frame)
+    int32_t pad;
+};
+
+struct FrameStat {
+    double snr_db;      // mpsk_snr_est_simple::snr()
+    double noise_db;    // ::noise()
+    double noise_lin;   // pow(10, noise_db / 10)  (equalizer.cc:281-287)
+};
+
+// One transport block to verify (lib/dtl/ofdm_adaptive_fec_decoder_impl.cc:161-181).
+struct TbDesc {
+    uint32_t bits_off;   // first decoded bit (1/byte) of the TB in the LDPC output buffer
+    uint32_t n_bits;     // tb_payload_len (user bits + 32 CRC bits)
+    uint32_t cw_first;   // first codeword index
+    uint32_t n_cw;
+};
+
+struct TbResult {
+    int32_t crc_ok;
+    int32_t avg_it;
+    int32_t user_bits;
+    int32_t pad;
+};
+
+} // namespace dtl

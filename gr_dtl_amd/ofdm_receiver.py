@@ -1,0 +1,281 @@
+"""Batched adaptive-OFDM receiver with the reference's hier-block interface.
+
+``ofdm_receiver(config)`` mirrors python/dtl/ofdm_receiver.py:11-56 (same constructor argument, same
+derived attributes) and ``ofdm_adaptive_rx.from_parameters(config_dict=None, **kwargs)`` mirrors
+python/dtl/ofdm_adaptive_rx.py:32-59.  Instead of wiring GNU Radio blocks, ``work(iq)`` hands a whole
+batch of samples (a device tensor) to the HIP pipeline behind the C ABI (include/dtl_rx.h) and returns
+the streams the reference hier block exposes on its output ports.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from . import ofdm_adaptive
+from .fec import _resolve
+from .ofdm_adaptive_config import (constellation_type_t, make_rx_config, ofdm_adaptive_rx_config)
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("fft_len", C.c_int32), ("cp_len", C.c_int32), ("frame_length", C.c_int32), ("has_fec", C.c_int32),
+                ("n_occ_sets", C.c_int32), ("max_occ", C.c_int32), ("occ_len", C.c_void_p), ("occ", C.c_void_p),
+                ("n_pilot_sets", C.c_int32), ("n_pilots", C.c_int32), ("pilot_carriers", C.c_void_p),
+                ("n_pilot_sym_sets", C.c_int32), ("pilot_symbols", C.c_void_p), ("sync_word1", C.c_void_p),
+                ("sync_word2", C.c_void_p), ("sync_threshold", C.c_float), ("eq_alpha", C.c_float),
+                ("use_sync_correct", C.c_int32), ("scramble_header", C.c_int32), ("llr_dist_mode", C.c_int32),
+                ("max_iterations", C.c_int32), ("bp_sigma", C.c_float), ("n_fec_codes", C.c_int32),
+                ("alist_texts", C.POINTER(C.c_char_p)), ("alist_lens", C.POINTER(C.c_size_t)),
+                ("n_mcs", C.c_int32), ("mcs_snr", C.c_void_p), ("mcs_cnst", C.c_void_p), ("mcs_fec", C.c_void_p),
+                ("initial_mcs", C.c_int32), ("decision_th", C.c_int32), ("hysteresis", C.c_double)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("trigger", C.c_int64), ("header_ok", C.c_int32), ("carr_offset", C.c_int32),
+                ("payload_len", C.c_int32), ("frame_no", C.c_int32), ("cnst", C.c_int32), ("fb_cnst", C.c_int32),
+                ("tb_no", C.c_int32), ("fec_fb", C.c_int32), ("tb_offset", C.c_int32), ("fec", C.c_int32),
+                ("tb_payload", C.c_int32), ("n_payload_syms", C.c_int32), ("payload_index", C.c_int32),
+                ("snr_db", C.c_double), ("noise", C.c_double), ("feedback_cnst", C.c_int32),
+                ("feedback_fec", C.c_int32), ("lost_frames", C.c_int32), ("cand", C.c_int32),
+                ("llr_offset", C.c_int64)]
+
+
+class TbInfo(C.Structure):
+    _fields_ = [("tb_no", C.c_int32), ("tb_payload", C.c_int32), ("crc_ok", C.c_int32), ("avg_it", C.c_int32),
+                ("user_bits", C.c_int32), ("pad", C.c_int32), ("out_offset", C.c_int64)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("n_frames", C.c_int64), ("n_payload_frames", C.c_int64), ("n_tbs", C.c_int64),
+                ("n_payload_bytes", C.c_int64), ("n_raw_triggers", C.c_int64), ("n_fixed_triggers", C.c_int64),
+                ("n_llr", C.c_int64), ("n_codewords", C.c_int64),
+                ("frames", C.POINTER(FrameInfo)), ("tbs", C.POINTER(TbInfo)),
+                ("raw_triggers", C.POINTER(C.c_int64)), ("fixed_triggers", C.POINTER(C.c_int64)),
+                ("trigger_angles", C.POINTER(C.c_float)),
+                ("d_payload", C.c_void_p), ("d_eq_hard", C.c_void_p), ("d_eq_soft", C.c_void_p),
+                ("d_soft_syms", C.c_void_p), ("d_llr", C.c_void_p), ("d_taps", C.c_void_p),
+                ("d_hdr_bits", C.c_void_p), ("d_metric", C.c_void_p), ("d_cw_bits", C.c_void_p),
+                ("d_cw_nit", C.c_void_p), ("stage_ms", C.c_double * 8),
+                ("frame_capacity", C.c_int32), ("hdr_bits", C.c_int32), ("frame_samples", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+WANT = {"eq_hard": 1, "eq_soft": 2, "soft_syms": 4, "hdr_bits": 8, "metric": 16}
+_FRAME_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4", C.c_double: "<f8"}[t]) for n, t in FrameInfo._fields_])
+_TB_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4"}[t]) for n, t in TbInfo._fields_])
+
+
+class rx_result:
+    """Outputs of one ``work`` call.  Port numbering follows ofdm_receiver (ofdm_receiver.py:18-20):
+    out0 ``payload`` (bytes), out1/out2 trigger positions (fixed / raw), out3 ``eq_hard``,
+    out4 ``soft_syms``, out5 ``sc_freq`` (held angle per raw trigger); message ports ``monitor`` /
+    ``feedback`` / ``header`` become the per-frame / per-TB record arrays."""
+
+    def __init__(self):
+        self.payload = None        # torch.uint8 (device)
+        self.frames = None         # numpy structured array, one row per visited trigger
+        self.tbs = None            # numpy structured array, one row per transport block
+        self.raw_triggers = None
+        self.fixed_triggers = None
+        self.sc_freq = None
+        self.eq_hard = self.eq_soft = self.soft_syms = self.llr = self.taps = self.hdr_bits = None
+        self.metric = self.cw_bits = self.cw_nit = None
+        self.stage_ms = None
+        self.n_payload_frames = 0
+        self.n_codewords = 0
+
+    def payload_bytes(self):
+        return self.payload.cpu().numpy()
+
+
+class ofdm_receiver:
+    """Adaptive OFDM Receiver (python/dtl/ofdm_receiver.py:11-56)."""
+
+    def __init__(self, config, name="rx"):
+        self.name = name
+        self.fft_len = config.fft_len
+        self.cp_len = config.cp_len
+        self.frame_length_tag_key = config.frame_length_tag_key
+        self.packet_length_tag_key = config.packet_length_tag_key
+        self.frame_no_tag_key = config.frame_no_tag_key
+        self.occupied_carriers = config.occupied_carriers
+        self.pilot_carriers = config.pilot_carriers
+        self.pilot_symbols = config.pilot_symbols
+        self.scramble_bits = config.scramble_bits
+        self.rolloff = config.rolloff
+        self.sync_threshold = config.sync_threshold
+        self.frame_length = config.frame_length
+        mc_schemes = list(zip(*config.mcs))[1]
+        cnsts = list(zip(*mc_schemes))[0]
+        self.constellations = list(set(cnsts))
+        self.use_sync_correct = config.use_sync_correct
+        self.fec = len(config.fec_codes)
+        self.codes_alist = []
+        self.codes_id = {}
+        if self.fec:
+            self.codes_alist = list(zip(*config.fec_codes))[1]
+            self.codes_id = {name: id + 1 for (id, name) in enumerate(list(zip(*config.fec_codes))[0])}
+        self.mcs = [(snr_th, (cnst, self.codes_id.get(code_name, 0))) for (snr_th, (cnst, code_name)) in config.mcs]
+        self.initial_mcs_id = config.initial_mcs_id
+        if [self.fft_len, self.fft_len] != [len(config.sync_word1), len(config.sync_word2)]:
+            raise ValueError("Length of sync sequence(s) must be FFT length.")
+        self.sync_words = [config.sync_word1, config.sync_word2]
+        self._config = config
+        self._h = C.c_void_p()
+        self._setup()
+
+    # -- construction -------------------------------------------------------------------------
+    def _setup(self):
+        L = _lib.lib()
+        self._declare(L)
+        cfg = self._config
+        self.header_len = 2 if self.fec else 1  # ofdm_receiver.py:66-68
+        self.frame_capacity = ofdm_adaptive.frame_capacity(self.frame_length, self.occupied_carriers)
+        occ_len = np.array([len(o) for o in self.occupied_carriers], dtype=np.int32)
+        max_occ = int(occ_len.max())
+        occ = np.zeros((len(self.occupied_carriers), max_occ), dtype=np.int32)
+        for i, o in enumerate(self.occupied_carriers):
+            occ[i, :len(o)] = o
+        pil = np.ascontiguousarray(self.pilot_carriers, dtype=np.int32)
+        psym = np.ascontiguousarray(np.asarray(self.pilot_symbols, dtype=np.complex64))
+        sw1 = np.ascontiguousarray(np.asarray(self.sync_words[0], dtype=np.complex64))
+        sw2 = np.ascontiguousarray(np.asarray(self.sync_words[1], dtype=np.complex64))
+        texts = []
+        for path in self.codes_alist:
+            with open(_resolve(path), "rb") as f:
+                texts.append(f.read())
+        n_codes = len(texts)
+        arr_texts = (C.c_char_p * max(n_codes, 1))(*texts) if n_codes else (C.c_char_p * 1)()
+        arr_lens = (C.c_size_t * max(n_codes, 1))(*[len(t) for t in texts]) if n_codes else (C.c_size_t * 1)()
+        mcs_snr = np.array([float(m[0]) for m in self.mcs], dtype=np.float64)
+        mcs_cnst = np.array([int(m[1][0]) for m in self.mcs], dtype=np.int32)
+        mcs_fec = np.array([int(m[1][1]) for m in self.mcs], dtype=np.int32)
+        c = _Cfg()
+        c.fft_len, c.cp_len, c.frame_length, c.has_fec = self.fft_len, self.cp_len, self.frame_length, int(bool(self.fec))
+        c.n_occ_sets, c.max_occ = occ.shape
+        c.occ_len, c.occ = occ_len.ctypes.data, occ.ctypes.data
+        c.n_pilot_sets, c.n_pilots = pil.shape
+        c.pilot_carriers = pil.ctypes.data
+        c.n_pilot_sym_sets = psym.shape[0]
+        c.pilot_symbols = psym.ctypes.data
+        c.sync_word1, c.sync_word2 = sw1.ctypes.data, sw2.ctypes.data
+        c.sync_threshold = float(self.sync_threshold)
+        c.eq_alpha = 0.1                      # ofdm_receiver.py:163
+        c.use_sync_correct = int(bool(self.use_sync_correct))
+        c.scramble_header = int(bool(self.scramble_bits))
+        c.llr_dist_mode = int(getattr(cfg, "llr_dist_mode", 0))
+        c.max_iterations = int(getattr(cfg, "ldpc_max_iterations", 15))
+        c.bp_sigma = float(getattr(cfg, "ldpc_sigma", 0.0))
+        c.n_fec_codes = n_codes
+        c.alist_texts = arr_texts
+        c.alist_lens = arr_lens
+        c.n_mcs = len(self.mcs)
+        c.mcs_snr, c.mcs_cnst, c.mcs_fec = mcs_snr.ctypes.data, mcs_cnst.ctypes.data, mcs_fec.ctypes.data
+        c.initial_mcs = int(self.initial_mcs_id)
+        c.decision_th = 5                     # ofdm_receiver.py:167
+        c.hysteresis = 1.0
+        self._keep = (occ_len, occ, pil, psym, sw1, sw2, arr_texts, arr_lens, mcs_snr, mcs_cnst, mcs_fec, texts)
+        _lib.check(L.dtl_rx_create(C.byref(c), C.byref(self._h)))
+
+    @staticmethod
+    def _declare(L):
+        if getattr(L, "_rx_declared", False):
+            return
+        L.dtl_rx_create.argtypes = [C.POINTER(_Cfg), C.POINTER(C.c_void_p)]
+        L.dtl_rx_destroy.argtypes = [C.c_void_p]
+        L.dtl_rx_destroy.restype = None
+        L.dtl_rx_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.POINTER(_Result)]
+        L.dtl_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L._rx_declared = True
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().dtl_rx_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def frame_samples(self):
+        return (2 + self.header_len + self.frame_length) * (self.fft_len + self.cp_len)
+
+    # -- batched work() -----------------------------------------------------------------------
+    def work(self, iq, want=(), copy_outputs=True):
+        """iq: complex64 CUDA tensor (1-D).  want: any of eq_hard, eq_soft, soft_syms, hdr_bits, metric,
+        llr, taps, cw.  Returns rx_result."""
+        import torch
+        if not (hasattr(iq, "is_cuda") and iq.is_cuda):
+            raise _lib.DtlError(_lib.ERR_NO_DEVICE, "ofdm_receiver.work needs a device tensor (no CPU fallback)")
+        if iq.dtype != torch.complex64:
+            raise ValueError("iq must be complex64")
+        iq = iq.contiguous().view(-1)
+        flags = 0
+        for w in want:
+            flags |= WANT.get(w, 0)
+        res = _Result()
+        st = _lib.current_stream_ptr()
+        _lib.check(_lib.lib().dtl_rx_process(self._h, iq.data_ptr(), iq.numel(), flags, st, C.byref(res)))
+        out = rx_result()
+        out.n_payload_frames = int(res.n_payload_frames)
+        out.n_codewords = int(res.n_codewords)
+        out.stage_ms = list(res.stage_ms)
+        nf, nt = int(res.n_frames), int(res.n_tbs)
+        out.frames = (np.ctypeslib.as_array(C.cast(res.frames, C.POINTER(C.c_uint8)), (nf * C.sizeof(FrameInfo),))
+                      .view(_FRAME_DTYPE).copy() if nf else np.zeros(0, _FRAME_DTYPE))
+        out.tbs = (np.ctypeslib.as_array(C.cast(res.tbs, C.POINTER(C.c_uint8)), (nt * C.sizeof(TbInfo),))
+                   .view(_TB_DTYPE).copy() if nt else np.zeros(0, _TB_DTYPE))
+        nr, nx = int(res.n_raw_triggers), int(res.n_fixed_triggers)
+        out.raw_triggers = np.ctypeslib.as_array(res.raw_triggers, (nr,)).copy() if nr else np.zeros(0, np.int64)
+        out.fixed_triggers = np.ctypeslib.as_array(res.fixed_triggers, (nx,)).copy() if nx else np.zeros(0, np.int64)
+        out.sc_freq = np.ctypeslib.as_array(res.trigger_angles, (nr,)).copy() if nr else np.zeros(0, np.float32)
+        if not copy_outputs:
+            out.n_payload_bytes = int(res.n_payload_bytes)
+            return out
+        dev = iq.device
+
+        def grab(ptr, shape, dtype):
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            if t.numel() and ptr:
+                _lib.check(_lib.lib().dtl_copy_device(t.data_ptr(), ptr, t.numel() * t.element_size(), st))
+            return t
+        out.payload = grab(res.d_payload, (int(res.n_payload_bytes),), torch.uint8)
+        npf, Lf, N, cap = out.n_payload_frames, self.frame_length, self.fft_len, int(res.frame_capacity)
+        if "eq_hard" in want:
+            out.eq_hard = grab(res.d_eq_hard, (npf, Lf, N), torch.complex64)
+        if "eq_soft" in want:
+            out.eq_soft = grab(res.d_eq_soft, (npf, Lf, N), torch.complex64)
+        if "soft_syms" in want:
+            out.soft_syms = grab(res.d_soft_syms, (npf, cap), torch.complex64)
+        if "llr" in want:
+            out.llr = grab(res.d_llr, (int(res.n_llr),), torch.float32)
+        if "taps" in want:
+            ncand = int(out.frames["cand"].max()) + 1 if nf else 0
+            out.taps = grab(res.d_taps, (ncand, N), torch.complex64) if ncand else None
+        if "hdr_bits" in want:
+            ncand = int(out.frames["cand"].max()) + 1 if nf else 0
+            out.hdr_bits = grab(res.d_hdr_bits, (ncand, int(res.hdr_bits)), torch.uint8)
+        if "metric" in want:
+            out.metric = grab(res.d_metric, (iq.numel(),), torch.float32)
+        if "cw" in want and out.n_codewords:
+            out.cw_nit = grab(res.d_cw_nit, (out.n_codewords,), torch.int32)
+        return out
+
+
+class ofdm_adaptive_rx:
+    """python/dtl/ofdm_adaptive_rx.py:32-59 (the feedback side-channel transmitter of
+    _setup_feedback_tx is outside the accelerated path)."""
+
+    @classmethod
+    def from_parameters(cls, config_dict=None, **kwargs):
+        cfg = make_rx_config(config_dict)
+        for key, val in kwargs.items():
+            if hasattr(cfg, key):
+                setattr(cfg, key, val)
+        return cls(cfg)
+
+    def __init__(self, config):
+        self.config = config
+        self.direct_rx = ofdm_receiver(config)
+
+    def work(self, iq, want=()):
+        return self.direct_rx.work(iq, want=want)

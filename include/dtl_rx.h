@@ -78,6 +78,117 @@ typedef struct dtl_cw_desc {
 int dtl_ldpc_decode_gather(const dtl_ldpc* h, const float* d_llr, const dtl_cw_desc* d_desc,
                            size_t ncw, uint8_t* d_bits, int32_t* d_nit, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Receiver  --  replaces the RX graph that dtl.ofdm_adaptive_rx / dtl.ofdm_receiver build
+ * (python/dtl/ofdm_adaptive_rx.py:32-59, python/dtl/ofdm_receiver.py:11-246): ofdm_sync_sc_cfb,
+ * frame_detect_bb, delay/oscillator/mixer, header_payload_demux, fft_vcc, ofdm_chanest_vcvc,
+ * header + payload frame equalisers, serializers, soft demapper, FEC decoder, fec_pack
+ * (or the hard demapper + frame_pack of the no-FEC tail).  One call = one GR "work" over a
+ * whole batch of frames; sample-stream state does not carry over between calls.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dtl_rx dtl_rx;
+
+/* dataclass ofdm_adaptive_config / ofdm_adaptive_rx_config (python/dtl/ofdm_adaptive_config.py:10-63) */
+typedef struct dtl_rx_cfg {
+    int32_t fft_len, cp_len, frame_length, has_fec;
+    int32_t n_occ_sets, max_occ;
+    const int32_t* occ_len;          /* n_occ_sets */
+    const int32_t* occ;              /* n_occ_sets x max_occ, signed carrier indices */
+    int32_t n_pilot_sets, n_pilots;
+    const int32_t* pilot_carriers;   /* n_pilot_sets x n_pilots */
+    int32_t n_pilot_sym_sets;
+    const float* pilot_symbols;      /* n_pilot_sym_sets x n_pilots complex (re,im) */
+    const float* sync_word1;         /* fft_len complex (re,im), shifted (DC at N/2) */
+    const float* sync_word2;
+    float sync_threshold, eq_alpha;
+    int32_t use_sync_correct, scramble_header;
+    int32_t llr_dist_mode;           /* 0: |x-s|^2/npwr (default), 1: |x-s|/npwr (calc_soft_dec variants) */
+    int32_t max_iterations;          /* LDPC BP, 15 */
+    float bp_sigma;                  /* 0 => sqrt(2) */
+    int32_t n_fec_codes;
+    const char* const* alist_texts;  /* fec_codes[i] -> FEC id i+1 (ofdm_receiver.py:47) */
+    const size_t* alist_lens;
+    int32_t n_mcs;                   /* feedback LUT (snr_th, (cnst, fec id)) */
+    const double* mcs_snr;
+    const int32_t* mcs_cnst;
+    const int32_t* mcs_fec;
+    int32_t initial_mcs;
+    int32_t decision_th;             /* 5 (ofdm_receiver.py:167) */
+    double hysteresis;               /* 1 */
+} dtl_rx_cfg;
+
+/* header fields = the "header_data" dict of packet_headerparser_b; snr/noise/feedback = what
+ * ofdm_adaptive_frame_equalizer_vcvc publishes per frame (tags, feedback_port, monitor) */
+typedef struct dtl_rx_frame_info {
+    int64_t trigger;
+    int32_t header_ok, carr_offset;
+    int32_t payload_len, frame_no, cnst, fb_cnst, tb_no, fec_fb, tb_offset, fec, tb_payload;
+    int32_t n_payload_syms, payload_index;
+    double snr_db, noise;
+    int32_t feedback_cnst, feedback_fec, lost_frames, cand;
+    int64_t llr_offset;
+} dtl_rx_frame_info;
+
+/* monitor message of ofdm_adaptive_fec_decoder (fec_decoder_impl.cc:183-195), per transport block */
+typedef struct dtl_rx_tb_info {
+    int32_t tb_no, tb_payload, crc_ok, avg_it, user_bits, pad;
+    int64_t out_offset;
+} dtl_rx_tb_info;
+
+enum dtl_rx_flags {
+    DTL_RX_WANT_EQ_HARD = 1,    /* out3 of ofdm_receiver: equalised + sliced symbols, L x N per frame */
+    DTL_RX_WANT_EQ_SOFT = 2,    /* out4 before the serializer: pre-slice symbols, L x N per frame     */
+    DTL_RX_WANT_SOFT_SYMS = 4,  /* serializer output (frame_capacity per frame)                        */
+    DTL_RX_WANT_HDR_BITS = 8,
+    DTL_RX_WANT_METRIC = 16     /* Schmidl-Cox metric per sample (debug)                               */
+};
+
+/* All pointers are owned by the handle and stay valid until the next dtl_rx_process / destroy.
+ * Host arrays: frames, tbs, raw_triggers, fixed_triggers, trigger_angles.  d_*: device. */
+typedef struct dtl_rx_result {
+    int64_t n_frames, n_payload_frames, n_tbs, n_payload_bytes, n_raw_triggers, n_fixed_triggers;
+    int64_t n_llr, n_codewords;
+    const dtl_rx_frame_info* frames;
+    const dtl_rx_tb_info* tbs;
+    const int64_t* raw_triggers;
+    const int64_t* fixed_triggers;
+    const float* trigger_angles;
+    const uint8_t* d_payload;   /* out0: packed user bytes of the CRC-ok TBs (or of every frame, no FEC) */
+    const float* d_eq_hard;     /* complex (re,im), n_payload_frames x L x N */
+    const float* d_eq_soft;
+    const float* d_soft_syms;   /* n_payload_frames x frame_capacity */
+    const float* d_llr;         /* soft bits, frame i at frames[..].llr_offset */
+    const float* d_taps;        /* per visited trigger: N taps handed to the payload equaliser */
+    const uint8_t* d_hdr_bits;
+    const float* d_metric;
+    const uint8_t* d_cw_bits;
+    const int32_t* d_cw_nit;
+    double stage_ms[8];
+    int32_t frame_capacity, hdr_bits, frame_samples, pad;
+} dtl_rx_result;
+
+int dtl_rx_create(const dtl_rx_cfg* cfg, dtl_rx** out);
+void dtl_rx_destroy(dtl_rx* h);
+/* d_iq: n_samples complex64 (re,im) on the device */
+int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t flags, void* stream,
+                   dtl_rx_result* out);
+
+/* device-to-device copy on `stream` (lets a host binding snapshot result buffers it does not own) */
+int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);
+
+/* Sequential integer helpers exported for unit tests (bit-exact targets):
+ * ofdm_adaptive_frame_detect_bb_impl::fix_sync on a sparse trigger list */
+int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, int64_t stream_len,
+                 int64_t* out, int64_t out_cap, int64_t* n_out);
+/* GR plateau_detector_fb(max_len, threshold) over a HOST metric array (the same host routine
+ * the pipeline runs on the kernel's threshold crossings) */
+int dtl_plateau_detect(const float* metric_host, int64_t n, float threshold, int32_t max_len,
+                       int64_t* out, int64_t out_cap, int64_t* n_out);
+/* ofdm_adaptive_feedback_decision::get_feedback over a sequence of SNR estimates */
+int dtl_feedback_sequence(int32_t n_mcs, const double* mcs_snr, const int32_t* mcs_cnst, const int32_t* mcs_fec,
+                          double hysteresis, int32_t decision_th, int32_t initial_mcs, const double* snr,
+                          int64_t n, int32_t* out_cnst, int32_t* out_fec);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,130 @@
+"""Full receive-path parity: HIP pipeline (through the C ABI) vs the CPU oracle on the same seeded
+IQ stream.  Integer outputs (trigger indices, header fields, carrier offsets, hard decisions, CRC
+flags, BP iteration counts, feedback decisions, payload bytes) must be identical; float outputs
+(equalised symbols, soft bits, SNR estimates) must agree within 1e-5 relative (north_star)."""
+import numpy as np
+import pytest
+
+from helpers import make_pair, make_stream, oracle_feedback
+
+RTOL = 1e-5
+
+
+def _close(got, want, rtol=RTOL, atol=0.0, what=""):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = np.maximum(np.abs(want), atol / max(rtol, 1e-30))
+    err = np.abs(got - want)
+    bad = err > rtol * scale + atol
+    # both infinite / NaN in the same place counts as equal
+    same_nonfinite = (~np.isfinite(got)) & (~np.isfinite(want)) & ((np.isnan(got) & np.isnan(want)) | (got == want))
+    bad &= ~same_nonfinite
+    assert not bad.any(), (what, int(bad.sum()), float(np.nanmax(np.where(bad, err / np.maximum(np.abs(want), 1e-30), 0))))
+
+
+def _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, want_llr=True):
+    import torch
+    rx = dtl.ofdm_receiver(pcfg)
+    want = ("eq_hard", "eq_soft", "soft_syms", "hdr_bits", "llr", "taps", "cw")
+    res = rx.work(torch.from_numpy(x).to(cuda), want=want)
+    ref = oracle.rx_stream(ocfg, code, x, feedback=oracle_feedback(oracle, pcfg, rx),
+                           want=("frames", "trig", "angle", "eq_hard", "eq_soft", "soft_syms", "llr", "hdr_bits", "taps"))
+    return rx, res, ref
+
+
+def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
+    # --- sync: trigger indices are integers -> exact; the held angle is a float
+    raw_ref = np.nonzero(ref["trig_raw"])[0]
+    fix_ref = np.nonzero(ref["trig_fixed"])[0]
+    np.testing.assert_array_equal(res.raw_triggers, raw_ref)
+    np.testing.assert_array_equal(res.fixed_triggers, fix_ref)
+    _close(res.sc_freq, ref["angle"][raw_ref], rtol=1e-4, atol=2e-6, what="sc angle")
+    # --- demux walk + header fields
+    assert len(res.frames) == ref["n_frames"]
+    N, L = ocfg.fft_len, ocfg.frame_length
+    pi = 0
+    occ_mask = np.zeros(N, bool)
+    for s in ocfg.occupied_carriers:
+        occ_mask[[((c + N if c < 0 else c) + N // 2) % N for c in s]] = True
+    pil_mask = np.zeros(N, bool)
+    for s in ocfg.pilot_carriers:
+        pil_mask[[((c + N if c < 0 else c) + N // 2) % N for c in s]] = True
+    used = occ_mask | pil_mask
+    frames = res.frames
+    eq_hard = res.eq_hard.cpu().numpy() if res.eq_hard is not None else None
+    eq_soft = res.eq_soft.cpu().numpy()
+    soft_syms = res.soft_syms.cpu().numpy()
+    llr = res.llr.cpu().numpy()
+    taps = res.taps.cpu().numpy()
+    hdr_bits = res.hdr_bits.cpu().numpy()
+    for i, rf in enumerate(ref["frames"]):
+        f = frames[i]
+        assert f["trigger"] == rf["trigger"] and f["header_ok"] == rf["header_ok"], i
+        assert f["carr_offset"] == rf["carr_offset"], i
+        if not rf["header_ok"]:
+            continue
+        np.testing.assert_array_equal(hdr_bits[f["cand"]], ref["hdr_bits"][i])
+        for k in ("payload_len", "frame_no", "cnst", "fb_cnst", "tb_no", "fec_fb", "tb_offset", "fec", "tb_payload"):
+            assert f[k] == rf["hdr"][k], (i, k)
+        assert f["n_payload_syms"] == rf["n_payload_syms"]
+        assert f["payload_index"] == pi
+        _close(taps[f["cand"]], ref["taps"][i], atol=1e-6 * N, what="taps")
+        # --- equaliser outputs
+        h_ref, s_ref = ref["eq_hard"][i], ref["eq_soft"][i]
+        np.testing.assert_array_equal(eq_hard[pi][:, used], h_ref[:, used])   # sliced symbols: exact
+        _close(eq_soft[pi], s_ref, atol=2e-6, what="eq_soft frame %d" % i)
+        _close(f["snr_db"], rf["snr_db"], rtol=1e-6, atol=1e-6, what="snr")
+        _close(f["noise"], rf["noise_lin"], rtol=1e-5, what="noise")
+        assert (f["feedback_cnst"], f["feedback_fec"], f["lost_frames"]) == (rf["fb_cnst"], rf["fb_fec"], rf["lost_frames"])
+        if rf["hdr"]["payload_len"]:
+            ns = min(rf["n_payload_syms"], ocfg.frame_capacity)
+            _close(soft_syms[pi][:ns], ref["soft_syms"][i][:ns], atol=2e-6, what="soft_syms")
+            if has_fec:
+                nb = ns * rf["hdr"]["cnst"]
+                got = llr[f["llr_offset"]:f["llr_offset"] + nb]
+                _close(got, ref["llr"][i][:nb], rtol=2e-5, atol=1e-4, what="llr frame %d" % i)
+        pi += 1
+    assert pi == res.n_payload_frames
+    # --- transport blocks / payload
+    assert len(res.tbs) == len(ref["tbs"])
+    for t, rt in zip(res.tbs, ref["tbs"]):
+        assert t["tb_no"] == rt["tb_no"] and t["crc_ok"] == rt["crc_ok"], (t, rt)
+        assert t["user_bits"] == rt["user_bits"]
+        if has_fec:
+            assert t["avg_it"] == rt["avg_it"], (t, rt)
+    if check_payload:
+        np.testing.assert_array_equal(res.payload.cpu().numpy(), ref["user_bytes"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cnst,esn0,nbytes", [(2, None, 3000), (2, 13.0, 6000), (1, 12.0, 2500), (3, 21.0, 6000),
+                                              (4, 24.0, 8000), (4, 21.0, 8000)])
+def test_fec_chain_matches_oracle_64(oracle, dtl, cuda, cnst, esn0, nbytes):
+    pcfg, ocfg, code = make_pair(oracle, dtl)
+    user, hdrs, x = make_stream(oracle, ocfg, code, cnst, nbytes, esn0, seed=100 + cnst)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
+    assert ref["n_frames"] >= 0.9 * len(hdrs)
+    _compare(rx, res, ref, ocfg, True)
+    if esn0 is None:
+        assert np.array_equal(ref["user_bytes"], user)
+
+
+@pytest.mark.gpu
+def test_no_fec_chain_matches_oracle(oracle, dtl, cuda):
+    """config #1: 64-pt FFT, BPSK, no FEC (plumbing)."""
+    pcfg, ocfg, code = make_pair(oracle, dtl, fec=None)
+    for cnst, esn0 in ((1, 14.0), (3, None), (4, 26.0)):
+        user, hdrs, x = make_stream(oracle, ocfg, None, cnst, 4000, esn0, seed=7 + cnst)
+        rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, None, x)
+        _compare(rx, res, ref, ocfg, False)
+        assert len(ref["tbs"]) > 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fft_len,frame_length,thr,esn0", [(256, 20, 0.985, 24.0), (1024, 10, 0.99, 27.0)])
+def test_fec_chain_matches_oracle_large_fft(oracle, dtl, cuda, fft_len, frame_length, thr, esn0):
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, sync_threshold=thr)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 4, 40000 if fft_len == 256 else 60000, esn0, seed=fft_len)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
+    assert ref["n_frames"] > 0.5 * len(hdrs)
+    _compare(rx, res, ref, ocfg, True)
