@@ -681,12 +681,12 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
 {
     if (n_frames <= 0) return DTL_OK;
     const size_t lds = payload_lds_bytes(t);
-    if (lds > 160 * 1024) { set_last_error("payload kernel: frame does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    if (lds > 159 * 1024) { set_last_error("payload kernel: frame does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
+    static size_t attr_lds = 64 * 1024;
+    if (lds > attr_lds) {
         DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(payload_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_lds = lds;
     }
     hipLaunchKernelGGL(payload_kernel, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
                        taps, stats, llr_off, llr, eq_hard, eq_soft, soft_syms, nofec_bytes, nofec_info,

@@ -60,9 +60,10 @@ class _Result(C.Structure):
                 ("pad", C.c_int32)]
 
 
+assert None is None
 WANT = {"eq_hard": 1, "eq_soft": 2, "soft_syms": 4, "hdr_bits": 8, "metric": 16}
-_FRAME_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4", C.c_double: "<f8"}[t]) for n, t in FrameInfo._fields_])
-_TB_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4"}[t]) for n, t in TbInfo._fields_])
+_FRAME_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4", C.c_double: "<f8"}[t]) for n, t in FrameInfo._fields_], align=True)
+_TB_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4"}[t]) for n, t in TbInfo._fields_], align=True)
 
 
 class rx_result:

@@ -97,7 +97,7 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cnst,esn0,nbytes", [(2, None, 3000), (2, 13.0, 6000), (1, 12.0, 2500), (3, 21.0, 6000),
+@pytest.mark.parametrize("cnst,esn0,nbytes", [(2, None, 3000), (2, 13.0, 6000), (1, 20.0, 2500), (3, 21.0, 6000),
                                               (4, 24.0, 8000), (4, 21.0, 8000)])
 def test_fec_chain_matches_oracle_64(oracle, dtl, cuda, cnst, esn0, nbytes):
     pcfg, ocfg, code = make_pair(oracle, dtl)
@@ -113,7 +113,7 @@ def test_fec_chain_matches_oracle_64(oracle, dtl, cuda, cnst, esn0, nbytes):
 def test_no_fec_chain_matches_oracle(oracle, dtl, cuda):
     """config #1: 64-pt FFT, BPSK, no FEC (plumbing)."""
     pcfg, ocfg, code = make_pair(oracle, dtl, fec=None)
-    for cnst, esn0 in ((1, 14.0), (3, None), (4, 26.0)):
+    for cnst, esn0 in ((1, 20.0), (3, None), (4, 26.0)):
         user, hdrs, x = make_stream(oracle, ocfg, None, cnst, 4000, esn0, seed=7 + cnst)
         rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, None, x)
         _compare(rx, res, ref, ocfg, False)
