@@ -60,6 +60,7 @@ def lib():
     L.dtl_ldpc_get_k.argtypes = [_vp]
     L.dtl_ldpc_get_permute.argtypes = [_vp, _vp]
     L.dtl_ldpc_encode_host.argtypes = [_vp, _vp, _vp]
+    L.dtl_ldpc_encode_batch_host.argtypes = [_vp, _vp, C.c_size_t, _vp]
     L.dtl_ldpc_decode_batch.argtypes = [_vp, _vp, C.c_size_t, _vp, _vp, _vp]
     L.dtl_ldpc_decode_gather.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
     _lib = L

@@ -90,6 +90,14 @@ int dtl_ldpc_encode_host(const dtl_ldpc* h, const uint8_t* data, uint8_t* out)
     return DTL_OK;
 }
 
+int dtl_ldpc_encode_batch_host(const dtl_ldpc* h, const uint8_t* data, size_t ncw, uint8_t* out)
+{
+    if (!h || !data || !out) return DTL_ERR_INVALID_ARG;
+    const int n = h->dec.code.n, k = h->dec.code.k;
+    for (size_t i = 0; i < ncw; i++) h->dec.code.encode(data + i * k, out + i * n);
+    return DTL_OK;
+}
+
 // device tables are created lazily so that creating/inspecting a code needs no GPU
 static int ensure_uploaded(const dtl_ldpc* h)
 {

@@ -273,7 +273,10 @@ struct TbAssembler {
 
 // ------------------------------------------------------------------ Receiver
 
-Receiver::~Receiver() = default;
+Receiver::~Receiver()
+{
+    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+}
 
 int Receiver::init()
 {
@@ -448,6 +451,7 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     if (!d_iq || n < 0) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
     if (n > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
     if (!uploaded_) DTL_TRY(upload_tables());
+    if (!ev_[0]) for (auto& e : ev_) DTL_HIP_CHECK(hipEventCreate(&e));
     const int N = cfg.fft_len, cp = cfg.cp_len, P = N + cp, h = cfg.header_len(), L = cfg.frame_length;
     const int hdr_syms = 2 + h;
     frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
@@ -699,9 +703,11 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
         }
         DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.p, fdesc.data(), size_t(n_frames) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
         DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.p, llr_off.data(), size_t(n_frames) * 4, hipMemcpyHostToDevice, st));
+        if (ev_[0]) DTL_HIP_CHECK(hipEventRecord(ev_[0], st));
         DTL_TRY(launch_payload(tab_, d_iq, n, d_frames_.as<FrameDesc>(), n_frames, d_segs_.as<CfoSegment>(), n_raw,
                                d_taps.as<cf32>(), d_stats_.as<FrameStat>(), d_llr_off_.as<uint32_t>(),
                                d_llr.as<float>(), eh, es, ss, nofec_bytes, nofec_inf, nofec_stride, st));
+        if (ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
         DTL_HIP_CHECK(hipMemcpyAsync(stats.data(), d_stats_.p, size_t(n_frames) * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
     }
     DTL_TRY(d_total_.ensure(16));
@@ -719,9 +725,11 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
             DTL_TRY(d_staging_.ensure(size_t(n_tbs) * stride));
             DTL_HIP_CHECK(hipMemcpyAsync(d_cwdesc_.p, cw_all.data(), cw_all.size() * sizeof(CwDesc), hipMemcpyHostToDevice, st));
             DTL_HIP_CHECK(hipMemcpyAsync(d_tbdesc_.p, tb_desc.data(), size_t(n_tbs) * sizeof(TbDesc), hipMemcpyHostToDevice, st));
+            if (ev_[2]) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
             for (auto& cr : code_ranges)
                 DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
                                                     d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st));
+            if (ev_[3]) DTL_HIP_CHECK(hipEventRecord(ev_[3], st));
             DTL_TRY(launch_tb_check(d_tbdesc_.as<TbDesc>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
                                     d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st));
             uint64_t max_out = 0;
@@ -743,6 +751,9 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
         DTL_HIP_CHECK(hipMemcpyAsync(&total_bytes, d_total_.p, 4, hipMemcpyDeviceToHost, st));
     }
     DTL_HIP_CHECK(hipStreamSynchronize(st));
+    stage_ms[6] = stage_ms[7] = 0.0;
+    if (ev_[0] && n_frames) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) stage_ms[7] = ms; }
+    if (ev_[2] && cfg.has_fec && n_tbs) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) stage_ms[6] = ms; }
     n_payload_bytes = total_bytes;
     stage_ms[4] = now_ms() - t0; t0 = now_ms();
 

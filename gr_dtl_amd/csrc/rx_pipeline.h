@@ -119,6 +119,7 @@ private:
     RxTables tab_{};
     DevBuf tab_blob_;
     bool uploaded_ = false;
+    hipEvent_t ev_[4] = { nullptr, nullptr, nullptr, nullptr }; // HIP events around the payload / LDPC kernels
     int capacity_ = 0;
     std::vector<std::unique_ptr<LdpcDecoder>> decoders_; // index 0 == nullptr ("no FEC")
     DevBuf d_edges_, d_counter_, d_trig_, d_angle_, d_cands_, d_segs_, d_recs_, d_frames_, d_stats_, d_llr_off_,

@@ -63,6 +63,14 @@ class ldpc_dec:
                                                   out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def encode_batch(self, data_bits):
+        """ncw x k bits -> ncw x n bits (host)."""
+        data = np.ascontiguousarray(data_bits, dtype=np.uint8).reshape(-1, self._k)
+        out = np.zeros((data.shape[0], self._n), dtype=np.uint8)
+        _lib.check(_lib.lib().dtl_ldpc_encode_batch_host(self._h, data.ctypes.data_as(C.c_void_p), data.shape[0],
+                                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # -- device paths -------------------------------------------------------------------
     def decode_batch(self, llr, out_bits=None, out_nit=None):
         """llr: CUDA float32 tensor [ncw, n] -> (bits uint8 [ncw, k], nit int32 [ncw])."""
@@ -96,6 +104,15 @@ class ldpc_dec:
         llr = torch.as_tensor(np.ascontiguousarray(in_data, dtype=np.float32)).view(1, -1).cuda()
         bits, nit = self.decode_batch(llr)
         return bits.cpu().numpy()[0], int(nit.cpu()[0])
+
+
+class ldpc_enc(ldpc_dec):
+    """gr::dtl::ldpc_enc (lib/dtl/ldpc_enc.h): same code object, host-side encode."""
+
+
+def make_ldpc_encoders(alist_fnames):
+    """lib/dtl/ldpc_enc.cc:23-32"""
+    return [None] + [ldpc_enc(f) for f in alist_fnames]
 
 
 def make_ldpc_decoders(alist_fnames, max_it=15):

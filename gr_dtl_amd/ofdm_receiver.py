@@ -83,6 +83,7 @@ class rx_result:
         self.metric = self.cw_bits = self.cw_nit = None
         self.stage_ms = None
         self.n_payload_frames = 0
+        self.n_payload_bytes = 0
         self.n_codewords = 0
 
     def payload_bytes(self):
@@ -229,8 +230,8 @@ class ofdm_receiver:
         out.raw_triggers = np.ctypeslib.as_array(res.raw_triggers, (nr,)).copy() if nr else np.zeros(0, np.int64)
         out.fixed_triggers = np.ctypeslib.as_array(res.fixed_triggers, (nx,)).copy() if nx else np.zeros(0, np.int64)
         out.sc_freq = np.ctypeslib.as_array(res.trigger_angles, (nr,)).copy() if nr else np.zeros(0, np.float32)
+        out.n_payload_bytes = int(res.n_payload_bytes)
         if not copy_outputs:
-            out.n_payload_bytes = int(res.n_payload_bytes)
             return out
         dev = iq.device
 

@@ -61,6 +61,8 @@ int dtl_ldpc_get_permute(const dtl_ldpc* h, int32_t* out_n); /* cldpc permutatio
  * on-air order [n-k check bits | k systematic bits].  Test-vector / TX helper. */
 int dtl_ldpc_encode_host(const dtl_ldpc* h, const uint8_t* data_k, uint8_t* out_n);
 
+int dtl_ldpc_encode_batch_host(const dtl_ldpc* h, const uint8_t* data, size_t ncw, uint8_t* out);
+
 /* fec_dec::decode(const float* in, int* nit, unsigned char* out) for ncw codewords:
  * d_llr  : ncw * n floats, positive = bit 1, on-air order (what ldpc_dec::decode receives)
  * d_bits : ncw * k bytes (0/1), the systematic bits
