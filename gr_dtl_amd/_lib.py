@@ -48,6 +48,13 @@ def lib():
         raise ImportError(
             "libdtl_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or gr_dtl_amd/csrc/build.sh -- there is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; importing torch first makes
+    # libdtl_hip.so bind to that copy instead of loading /opt/rocm's next to it (two runtimes do not
+    # share the device).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     L.dtl_last_error.restype = C.c_char_p
     L.dtl_version.restype = C.c_char_p
