@@ -27,8 +27,9 @@ def constellation_points(cnst):
         return np.array([-s - 1j * s, s - 1j * s, -s + 1j * s, s + 1j * s], dtype=np.complex64)
     if cnst == 3:
         a = np.float32(np.pi / 8.0)
-        m = np.array([1, 7, 15, 9, 3, 5, 13, 11])
-        return (np.cos(m * a) + 1j * np.sin(m * a)).astype(np.complex64)
+        m = np.array([1, 7, 15, 9, 3, 5, 13, 11], dtype=np.float32)
+        ang = (m * a).astype(np.float64)         # float product, then cos/sin in double (as the C++ table)
+        return (np.cos(ang).astype(np.float32) + 1j * np.sin(ang).astype(np.float32)).astype(np.complex64)
     if cnst == 4:
         level = np.sqrt(np.float32(0.1))
         i = np.arange(16)
