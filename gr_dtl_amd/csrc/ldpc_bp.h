@@ -27,6 +27,12 @@ struct LdpcTables {
     const uint16_t* sys_src;   // data[i] = estimate[sys_src[i]]     (cldpc::get_systematic_bits)
 };
 
+// LDS plan of the node-parallel kernel: byte offsets of the shared index tables and of the
+// per-wave slices inside the workgroup's dynamic LDS
+struct NpShared {
+    int row_ptr, edge_var, col_ptr, col_edge, perm, sys_src, wave_base, wave_stride;
+};
+
 class LdpcDecoder {
 public:
     LdpcCode code;
@@ -44,6 +50,12 @@ public:
 private:
     LdpcTables t_{};
     void* blob_ = nullptr;
+    // node-parallel kernel (normal path)
+    NpShared np_sh_{};
+    const uint16_t* np_col_ptr_ = nullptr;
+    const uint16_t* np_perm_ = nullptr;
+    size_t np_lds_ = 0;
+    bool np_ok_ = false;
 };
 
 } // namespace dtl

@@ -131,64 +131,81 @@ __device__ uint32_t crc_bits(const uint8_t* data, int len, int nbits, uint32_t p
 
 // ------------------------------------------------------------------------------------------
 // K1: Schmidl & Cox timing metric (GR ofdm_sync_sc_cfb as wired at ofdm_receiver.py:71-72).
-// Each thread slides the two windows over a strip of kStrip samples, sums in double, and emits
-// the threshold crossings ("edges") of the metric; plateau logic is sequential and runs on host.
+// A workgroup owns kSyncTile output samples.  It stages tile + N+1 samples of history in LDS,
+// forms c[j] = r[j] conj(r[j-N/2]) and e[j] = |r[j]|^2 in float (as the reference's multiply /
+// mag-squared blocks do), builds inclusive prefix sums of c and 0.5 e in DOUBLE with one block
+// scan, and reads every window sum as a difference of two prefixes:
+//   P[n] = -(S_c[n] - S_c[n-N/2]),  E[n] = S_e[n] - S_e[n-N],  metric = |P|^2 / E^2   (float).
+// Only the threshold crossings ("edges") leave the chip; plateau logic is sequential (host).
 // ------------------------------------------------------------------------------------------
 constexpr int kSyncThreads = 256;
+constexpr int kSyncTile = 1024;
 
 __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
-                                                                 int N, int strip, float thr,
+                                                                 int N, float thr,
                                                                  unsigned long long* __restrict__ edges,
                                                                  unsigned int* __restrict__ n_edges,
                                                                  unsigned int max_edges,
                                                                  float* __restrict__ metric_out)
 {
-    extern __shared__ cf32 tile[]; // N + strip*threads + 1 samples, tile[j] = iq[t0 - N - 1 + j]
+    extern __shared__ double sync_smem[];
     const int half = N / 2;
-    const int64_t t0 = int64_t(blockIdx.x) * strip * kSyncThreads;
-    const int tile_len = N + 1 + strip * kSyncThreads;
-    for (int j = threadIdx.x; j < tile_len; j += kSyncThreads) {
-        const int64_t src = t0 - N - 1 + j;
+    const int M = kSyncTile + N + 1;               // prefix arrays cover samples j0 .. j0+M-1
+    const int64_t t0 = int64_t(blockIdx.x) * kSyncTile;
+    const int64_t j0 = t0 - N - 1;
+    double* Sr = sync_smem;                        // prefix of c.re
+    double* Si = Sr + M;                           // prefix of c.im
+    double* Se = Si + M;                           // prefix of 0.5 * e
+    cf32* raw = reinterpret_cast<cf32*>(Se + M);   // samples j0-N/2 .. j0+M-1, coalesced staging
+    __shared__ double wave_tot[3][kSyncThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (M + kSyncThreads - 1) / kSyncThreads; // consecutive elements per thread
+    const int lo = tid * per, hi = min(M, lo + per);
+    for (int q = tid; q < M + half; q += kSyncThreads) {
+        const int64_t j = j0 - half + q;
         cf32 v = { 0.0f, 0.0f };
-        if (src >= 0 && src < n) v = iq[src];
-        tile[j] = v;
+        if (j >= 0 && j < n) v = iq[j];
+        raw[q] = v;
     }
     __syncthreads();
-    const int64_t first = t0 + int64_t(threadIdx.x) * strip; // first output sample of this thread
-    if (first >= n) return;
-    // sample index m lives at tile[m - t0 + N + 1]
-    auto at = [&](int64_t m) -> cf32 { return tile[int(m - t0) + N + 1]; };
-    auto corr = [&](int64_t m) -> cf32 { // c[m] = r[m] * conj(r[m - N/2]) in float
-        const cf32 a = at(m), b = at(m - half);
-        return { a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im };
-    };
-    // window sums ending at sample first-1 (so the thread also knows the metric just before its strip)
-    double pr = 0, pi = 0, en = 0;
-    const int64_t n0 = first - 1;
-    for (int m = 0; m < half; m++) {
-        const cf32 c = corr(n0 - m);
-        pr += c.re; pi += c.im;
+    // thread-local inclusive prefix over its run of consecutive elements
+    double ar = 0, ai = 0, ae = 0;
+    for (int q = lo; q < hi; q++) {
+        const cf32 a = raw[q + half], b = raw[q];
+        const float cr = a.re * b.re + a.im * b.im, ci = a.im * b.re - a.re * b.im;
+        ar += double(cr); ai += double(ci);
+        ae += double(0.5f * (a.re * a.re + a.im * a.im));
+        Sr[q] = ar; Si[q] = ai; Se[q] = ae;
     }
-    for (int m = 0; m < N; m++) {
-        const cf32 a = at(n0 - m);
-        en += 0.5f * (a.re * a.re + a.im * a.im);
+    // exclusive scan of the per-thread totals: wave shuffle scan + cross-wave fix-up
+    double xr = ar, xi = ai, xe = ae;
+    for (int o = 1; o < 64; o <<= 1) {
+        const double tr = __shfl_up(xr, o), ti = __shfl_up(xi, o), te = __shfl_up(xe, o);
+        if (lane >= o) { xr += tr; xi += ti; xe += te; }
     }
-    auto metric_of = [&]() -> float {
-        const float Pr = float(-pr), Pi = float(-pi), E = float(en);
+    if (lane == 63) { wave_tot[0][wid] = xr; wave_tot[1][wid] = xi; wave_tot[2][wid] = xe; }
+    __syncthreads();
+    double br = xr - ar, bi = xi - ai, be = xe - ae;          // exclusive within the wave
+    for (int w = 0; w < wid; w++) { br += wave_tot[0][w]; bi += wave_tot[1][w]; be += wave_tot[2][w]; }
+    for (int q = lo; q < hi; q++) { Sr[q] += br; Si[q] += bi; Se[q] += be; }
+    __syncthreads();
+    // metric for samples m = t0-1 .. t0+tile-1 (index q = m - j0); thread owns tile/threads consecutive m
+    constexpr int kOut = kSyncTile / kSyncThreads;
+    const int q_first = N + 1 + tid * kOut;                   // q of the thread's first output sample
+    auto metric_at = [&](int q) -> float {
+        const float Pr = float(-(Sr[q] - Sr[q - half])), Pi = float(-(Si[q] - Si[q - half]));
+        const float E = float(Se[q] - Se[q - N]);
         const float num = Pr * Pr + Pi * Pi;
         return num / (E * E);
     };
-    bool prev = (n0 >= 0) ? (metric_of() >= thr) : false;
-    for (int s = 0; s < strip; s++) {
-        const int64_t m = first + s;
+    const int64_t m_first = t0 + int64_t(tid) * kOut;
+    if (m_first >= n) return;
+    bool prev = (m_first - 1 >= 0) ? (metric_at(q_first - 1) >= thr) : false;
+#pragma unroll
+    for (int s = 0; s < kOut; s++) {
+        const int64_t m = m_first + s;
         if (m >= n) break;
-        const cf32 cn = corr(m), co = corr(m - half);
-        pr += cn.re; pr -= co.re;
-        pi += cn.im; pi -= co.im;
-        const cf32 a = at(m), o = at(m - N);
-        en += 0.5f * (a.re * a.re + a.im * a.im);
-        en -= 0.5f * (o.re * o.re + o.im * o.im);
-        const float mt = metric_of();
+        const float mt = metric_at(q_first + s);
         if (metric_out) metric_out[m] = mt;
         const bool cur = mt >= thr;
         if (cur != prev) {
@@ -577,6 +594,44 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
     }
 }
 
+// K9: transport-block reassembly as index arithmetic -- one CwDesc per codeword from the TB recipe.
+// Codeword i carries k_i = floor(P/n) + (i < P mod n) payload bits (the iterated ceil split of
+// tb_decoder.cc:168-172) and starts at receive-buffer position i*ncheck + sum_{j<i} k_j.
+__global__ __launch_bounds__(64) void expand_cw_kernel(const TbGather* __restrict__ tbs, int n_tbs,
+                                                      CwDesc* __restrict__ out)
+{
+    const int tb = blockIdx.x;
+    if (tb >= n_tbs) return;
+    const TbGather g = tbs[tb];
+    const int q = g.n_cw > 0 ? g.tb_payload / g.n_cw : 0, r = g.n_cw > 0 ? g.tb_payload % g.n_cw : 0;
+    for (int i = threadIdx.x; i < g.n_cw; i += 64) {
+        const int k_i = q + (i < r ? 1 : 0);
+        const int before = i * q + min(i, r);
+        const int k_used = min(max(k_i, 0), int(g.k));
+        const long want = g.ncheck + k_used;
+        long rcv_idx = long(i) * g.ncheck + before;
+        CwDesc d;
+        d.out_off = g.bits_off + uint32_t(before);
+        d.k_used = uint16_t(k_used);
+        int si = 0;
+        long seg_start = 0;
+        while (si < g.n_seg && seg_start + g.seg_len[si] <= rcv_idx) { seg_start += g.seg_len[si]; si++; }
+        if (si >= g.n_seg || g.seg_off[si] == 0xFFFFFFFFu) {
+            d.llr_off0 = 0; d.len0 = 0; d.llr_off1 = 0xFFFFFFFFu;
+        } else {
+            const long in_seg = rcv_idx - seg_start;
+            const long avail0 = g.seg_len[si] - in_seg;
+            d.llr_off0 = g.seg_off[si] + uint32_t(in_seg);
+            if (avail0 >= want) { d.len0 = uint16_t(want); d.llr_off1 = 0xFFFFFFFFu; }
+            else {
+                d.len0 = uint16_t(avail0);
+                d.llr_off1 = (si + 1 < g.n_seg) ? g.seg_off[si + 1] : 0xFFFFFFFFu;
+            }
+        }
+        out[g.cw_first + i] = d;
+    }
+}
+
 // Exclusive scan of the per-block output lengths (single workgroup; block counts are O(frames)).
 __global__ __launch_bounds__(1024) void scan_lengths_kernel(const int32_t* __restrict__ len, int n,
                                                            uint32_t* __restrict__ offs,
@@ -628,14 +683,17 @@ __global__ void nofec_lengths_kernel(const int32_t* __restrict__ info, int n, in
 int launch_sync_edges(const cf32* iq, int64_t n, int N, float thr, unsigned long long* edges,
                       unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st)
 {
-    // strip: work per thread; tile = N + 1 + strip*256 samples of 8 bytes must fit LDS comfortably
-    int strip = N <= 64 ? 16 : 32;
-    const size_t lds = size_t(N + 1 + strip * kSyncThreads) * sizeof(cf32);
-    const int64_t per_block = int64_t(strip) * kSyncThreads;
-    const int64_t grid = (n + per_block - 1) / per_block;
+    const size_t lds = size_t(kSyncTile + N + 1) * 3 * sizeof(double) + size_t(kSyncTile + N + 1 + N / 2) * sizeof(cf32);
+    const int64_t grid = (n + kSyncTile - 1) / kSyncTile;
     if (grid <= 0) return DTL_OK;
-    hipLaunchKernelGGL(sync_edges_kernel, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, N, strip, thr,
-                       edges, n_edges, max_edges, metric_out);
+    static size_t attr_lds = 64 * 1024;
+    if (lds > attr_lds) {
+        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sync_edges_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(sync_edges_kernel, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, N, thr, edges,
+                       n_edges, max_edges, metric_out);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }
@@ -701,6 +759,14 @@ int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int
     if (n_tbs <= 0) return DTL_OK;
     hipLaunchKernelGGL(tb_check_kernel, dim3(n_tbs), dim3(64), 0, st, tbs, n_tbs, bits, nit, staging, stride, res);
     hipLaunchKernelGGL(tb_lengths_kernel, dim3((n_tbs + 255) / 256), dim3(256), 0, st, res, n_tbs, len);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+int launch_expand_cw(const TbGather* tbs, int n_tbs, CwDesc* out, hipStream_t st)
+{
+    if (n_tbs <= 0) return DTL_OK;
+    hipLaunchKernelGGL(expand_cw_kernel, dim3(n_tbs), dim3(64), 0, st, tbs, n_tbs, out);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

@@ -192,33 +192,26 @@ void FeedbackDecision::get(double snr, int* cnst, int* fec)
 
 namespace {
 
-struct Seg {
-    uint32_t off;
-    int len;
-};
-
 // tb_decoder (lib/dtl/tb_decoder.cc) with the receive buffer expressed as source segments of the
-// soft-bit stream instead of copied floats.
+// soft-bit stream instead of copied floats; decode() emits one gather recipe per TB, the per-codeword
+// descriptors are expanded on the device (expand_cw_kernel).
 struct TbAssembler {
-    struct PendingTb {
-        int code;               // decoder index
-        int tb_no, tb_payload;  // as reported by on_data_ready
-        uint32_t n_bits;
-        std::vector<CwDesc> cws; // out_off relative to the TB's first bit
-    };
+    struct Seg { uint32_t off; int len; };
+    struct Done { TbGather g; int code, tb_no, tb_payload; };
     std::vector<Seg> rcv;
     long rcv_size = 0, rcv_cap = 0, buf_idx = 0;
     int tb_number = -1;
     bool have_info = false;
     int info_tb_payload = 0, info_code = 0;
-    std::vector<PendingTb> done;
+    std::vector<Done> done;
+    bool overflow = false; // a TB needed more than 4 source segments
 
     void append(uint32_t base, long lo, long hi, long in_len)
     {
         if (hi <= lo) return;
         // reads past the frame's soft bits (reference: whatever follows in the buffer) are
         // defined as "never received": a gap segment, decoded as soft value 0
-        long h2 = std::min(hi, in_len);
+        const long h2 = std::min(hi, in_len);
         if (h2 > lo) rcv.push_back({ uint32_t(base + lo), int(h2 - lo) });
         if (hi > std::max(h2, lo)) rcv.push_back({ 0xFFFFFFFFu, int(hi - std::max(h2, lo)) });
         rcv_size += hi - lo;
@@ -227,45 +220,20 @@ struct TbAssembler {
 
     void decode(int tb_len, int n, int k, int tb_no, int tb_payload)
     {
-        PendingTb tb;
-        tb.code = info_code; tb.tb_no = tb_no; tb.tb_payload = tb_payload;
-        tb.n_bits = uint32_t(std::max(info_tb_payload, 0));
-        const int ncheck = n - k;
-        int payload_len = info_tb_payload;
-        long rcv_idx = 0;
-        uint32_t d_idx = 0;
-        size_t si = 0; long seg_start = 0; // segment cursor
-        for (int i = 0; i < tb_len; ++i) {
-            int k_ = payload_len / (tb_len - i);
-            if (payload_len % (tb_len - i)) ++k_;
-            payload_len -= k_;
-            const int k_used = std::min(std::max(k_, 0), k);
-            const long want = ncheck + k_used;
-            CwDesc d{};
-            d.out_off = d_idx;
-            d.k_used = uint16_t(k_used);
-            // locate rcv_idx in the segment list
-            while (si < rcv.size() && seg_start + rcv[si].len <= rcv_idx) { seg_start += rcv[si].len; si++; }
-            if (si >= rcv.size()) { // nothing received for this codeword: all soft bits "not sent"
-                d.llr_off0 = 0; d.len0 = 0; d.llr_off1 = 0xFFFFFFFFu;
-            } else {
-                const long in_seg = rcv_idx - seg_start;
-                const long avail0 = rcv[si].len - in_seg;
-                if (rcv[si].off == 0xFFFFFFFFu) { d.llr_off0 = 0; d.len0 = 0; d.llr_off1 = 0xFFFFFFFFu; }
-                else {
-                    d.llr_off0 = uint32_t(rcv[si].off + in_seg);
-                    if (avail0 >= want) { d.len0 = uint16_t(want); d.llr_off1 = 0xFFFFFFFFu; }
-                    else {
-                        d.len0 = uint16_t(avail0);
-                        d.llr_off1 = (si + 1 < rcv.size()) ? rcv[si + 1].off : 0xFFFFFFFFu;
-                    }
-                }
-            }
-            tb.cws.push_back(d);
-            rcv_idx += ncheck + k_;
-            d_idx += uint32_t(std::max(k_, 0));
+        Done d{};
+        d.code = info_code; d.tb_no = tb_no; d.tb_payload = tb_payload;
+        TbGather& g = d.g;
+        g.n_seg = int16_t(std::min<size_t>(rcv.size(), 4));
+        if (rcv.size() > 4) overflow = true;
+        for (int i = 0; i < 4; i++) {
+            g.seg_off[i] = i < g.n_seg ? rcv[i].off : 0xFFFFFFFFu;
+            g.seg_len[i] = i < g.n_seg ? rcv[i].len : 0;
         }
-        done.push_back(std::move(tb));
+        g.tb_payload = std::max(info_tb_payload, 0);
+        g.n_cw = int16_t(tb_len);
+        g.ncheck = int16_t(n - k);
+        g.k = int16_t(k);
+        done.push_back(d);
     }
 };
 
@@ -589,6 +557,42 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
         size_t fidx = 0;
         for (auto& fi : frames) if (fi.payload_index >= 0) { fi.llr_offset = llr_off[fidx]; fidx++; }
     }
+    // ---- phase B starts now: the payload kernel only needs the frame descriptors and the soft-bit
+    // offsets; the transport-block bookkeeping below runs on the host while it executes.
+    std::vector<FrameStat> stats(n_frames);
+    std::vector<int32_t> nofec_info(size_t(n_frames) * 2, 0);
+    uint32_t total_bytes = 0;
+    const int nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
+    if (n_frames) {
+        DTL_TRY(d_frames_.ensure(size_t(n_frames) * sizeof(FrameDesc)));
+        DTL_TRY(d_stats_.ensure(size_t(n_frames) * sizeof(FrameStat)));
+        DTL_TRY(d_llr_off_.ensure(size_t(n_frames) * 4));
+        DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
+        cf32 *eh = nullptr, *es = nullptr, *ss = nullptr;
+        if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_frames) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
+        if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_frames) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
+        if (flags & RX_WANT_SOFT_SYMS) {
+            DTL_TRY(d_soft_syms.ensure(size_t(n_frames) * capacity_ * sizeof(cf32)));
+            DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_frames) * capacity_ * sizeof(cf32), st));
+            ss = d_soft_syms.as<cf32>();
+        }
+        uint8_t* nofec_bytes = nullptr;
+        int32_t* nofec_inf = nullptr;
+        if (!cfg.has_fec) {
+            DTL_TRY(d_staging_.ensure(size_t(n_frames) * nofec_stride));
+            DTL_TRY(d_nofec_info_.ensure(size_t(n_frames) * 8));
+            DTL_HIP_CHECK(hipMemsetAsync(d_nofec_info_.p, 0, size_t(n_frames) * 8, st));
+            nofec_bytes = d_staging_.as<uint8_t>();
+            nofec_inf = d_nofec_info_.as<int32_t>();
+        }
+        DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.p, fdesc.data(), size_t(n_frames) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.p, llr_off.data(), size_t(n_frames) * 4, hipMemcpyHostToDevice, st));
+        if (ev_[0]) DTL_HIP_CHECK(hipEventRecord(ev_[0], st));
+        DTL_TRY(launch_payload(tab_, d_iq, n, d_frames_.as<FrameDesc>(), n_frames, d_segs_.as<CfoSegment>(), n_raw,
+                               d_taps.as<cf32>(), d_stats_.as<FrameStat>(), d_llr_off_.as<uint32_t>(),
+                               d_llr.as<float>(), eh, es, ss, nofec_bytes, nofec_inf, nofec_stride, st));
+        if (ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
+    }
     TbAssembler asmb;
     if (cfg.has_fec) {
         int max_n = 0, max_bps = 0;
@@ -649,82 +653,59 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
             }
         }
     }
-    // order the codewords: grouped per LDPC code, TB order inside a group
+    if (asmb.overflow) { set_last_error("transport block spread over more than 4 stream segments"); return DTL_ERR_UNSUPPORTED; }
+    // global codeword order: grouped per LDPC code, TB order inside a group
     const int n_tbs = int(asmb.done.size());
-    std::vector<CwDesc> cw_all;
+    std::vector<TbGather> gathers(n_tbs);
     std::vector<TbDesc> tb_desc(n_tbs);
-    std::vector<std::pair<int, std::pair<size_t, size_t>>> code_ranges; // code -> [first, count) in cw_all
+    std::vector<std::pair<int, std::pair<size_t, size_t>>> code_ranges; // code -> [first, count)
+    size_t n_cw_total = 0;
+    uint64_t max_out_bytes = 0;
+    int stride = 16;
     {
         uint32_t bits_base = 0;
-        std::vector<uint32_t> tb_bits_off(n_tbs);
-        for (int tix = 0; tix < n_tbs; tix++) { tb_bits_off[tix] = bits_base; bits_base += asmb.done[tix].n_bits + 8; }
-        for (int code = 1; code < int(decoders_.size()); code++) {
-            const size_t first = cw_all.size();
-            for (int tix = 0; tix < n_tbs; tix++) {
-                auto& tb = asmb.done[tix];
-                if (tb.code != code) continue;
-                tb_desc[tix] = { tb_bits_off[tix], tb.n_bits, uint32_t(cw_all.size()), uint32_t(tb.cws.size()) };
-                for (auto d : tb.cws) { d.out_off += tb_bits_off[tix]; cw_all.push_back(d); }
-            }
-            if (cw_all.size() > first) code_ranges.push_back({ code, { first, cw_all.size() - first } });
+        for (int tix = 0; tix < n_tbs; tix++) {
+            asmb.done[tix].g.bits_off = bits_base;
+            bits_base += uint32_t(asmb.done[tix].g.tb_payload) + 8;
+            max_out_bytes += uint64_t(asmb.done[tix].g.tb_payload) / 8;
+            stride = std::max<int>(stride, asmb.done[tix].g.tb_payload / 8 + 8);
         }
-        n_codewords = int64_t(cw_all.size());
+        for (int code = 1; code < int(decoders_.size()); code++) {
+            const size_t first = n_cw_total;
+            for (int tix = 0; tix < n_tbs; tix++) {
+                auto& d = asmb.done[tix];
+                if (d.code != code) continue;
+                d.g.cw_first = uint32_t(n_cw_total);
+                n_cw_total += size_t(d.g.n_cw);
+            }
+            if (n_cw_total > first) code_ranges.push_back({ code, { first, n_cw_total - first } });
+        }
+        for (int tix = 0; tix < n_tbs; tix++) {
+            gathers[tix] = asmb.done[tix].g;
+            tb_desc[tix] = { gathers[tix].bits_off, uint32_t(gathers[tix].tb_payload), gathers[tix].cw_first, uint32_t(gathers[tix].n_cw) };
+        }
+        n_codewords = int64_t(n_cw_total);
+        stride = (stride + 15) & ~15;
         DTL_TRY(d_cw_bits.ensure(size_t(bits_base) + 4096));
     }
     stage_ms[3] = now_ms() - t0; t0 = now_ms();
 
-    // ---- phase B: payload kernel -> LDPC -> TB check -> compaction
-    std::vector<FrameStat> stats(n_frames);
+    // ---- LDPC -> TB check -> compaction (the payload kernel is already running)
     std::vector<TbResult> tb_res(n_tbs);
-    std::vector<int32_t> nofec_info(size_t(n_frames) * 2, 0);
-    uint32_t total_bytes = 0;
-    const int nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
-    if (n_frames) {
-        DTL_TRY(d_frames_.ensure(size_t(n_frames) * sizeof(FrameDesc)));
-        DTL_TRY(d_stats_.ensure(size_t(n_frames) * sizeof(FrameStat)));
-        DTL_TRY(d_llr_off_.ensure(size_t(n_frames) * 4));
-        DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
-        cf32 *eh = nullptr, *es = nullptr, *ss = nullptr;
-        if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_frames) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
-        if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_frames) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
-        if (flags & RX_WANT_SOFT_SYMS) {
-            DTL_TRY(d_soft_syms.ensure(size_t(n_frames) * capacity_ * sizeof(cf32)));
-            DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_frames) * capacity_ * sizeof(cf32), st));
-            ss = d_soft_syms.as<cf32>();
-        }
-        uint8_t* nofec_bytes = nullptr;
-        int32_t* nofec_inf = nullptr;
-        if (!cfg.has_fec) {
-            DTL_TRY(d_staging_.ensure(size_t(n_frames) * nofec_stride));
-            DTL_TRY(d_nofec_info_.ensure(size_t(n_frames) * 8));
-            DTL_HIP_CHECK(hipMemsetAsync(d_nofec_info_.p, 0, size_t(n_frames) * 8, st));
-            nofec_bytes = d_staging_.as<uint8_t>();
-            nofec_inf = d_nofec_info_.as<int32_t>();
-        }
-        DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.p, fdesc.data(), size_t(n_frames) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
-        DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.p, llr_off.data(), size_t(n_frames) * 4, hipMemcpyHostToDevice, st));
-        if (ev_[0]) DTL_HIP_CHECK(hipEventRecord(ev_[0], st));
-        DTL_TRY(launch_payload(tab_, d_iq, n, d_frames_.as<FrameDesc>(), n_frames, d_segs_.as<CfoSegment>(), n_raw,
-                               d_taps.as<cf32>(), d_stats_.as<FrameStat>(), d_llr_off_.as<uint32_t>(),
-                               d_llr.as<float>(), eh, es, ss, nofec_bytes, nofec_inf, nofec_stride, st));
-        if (ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
-        DTL_HIP_CHECK(hipMemcpyAsync(stats.data(), d_stats_.p, size_t(n_frames) * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
-    }
     DTL_TRY(d_total_.ensure(16));
     if (cfg.has_fec) {
-        int stride = 16;
-        for (auto& tb : asmb.done) stride = std::max<int>(stride, int(tb.n_bits / 8) + 8);
-        stride = (stride + 15) & ~15;
         if (n_tbs) {
-            DTL_TRY(d_cwdesc_.ensure(cw_all.size() * sizeof(CwDesc)));
-            DTL_TRY(d_cw_nit.ensure(cw_all.size() * 4));
+            DTL_TRY(d_cwdesc_.ensure(n_cw_total * sizeof(CwDesc)));
+            DTL_TRY(d_cw_nit.ensure(n_cw_total * 4));
+            DTL_TRY(d_tbgather_.ensure(size_t(n_tbs) * sizeof(TbGather)));
             DTL_TRY(d_tbdesc_.ensure(size_t(n_tbs) * sizeof(TbDesc)));
             DTL_TRY(d_tbres_.ensure(size_t(n_tbs) * sizeof(TbResult)));
             DTL_TRY(d_len_.ensure(size_t(n_tbs) * 4));
             DTL_TRY(d_offs_.ensure(size_t(n_tbs) * 4));
             DTL_TRY(d_staging_.ensure(size_t(n_tbs) * stride));
-            DTL_HIP_CHECK(hipMemcpyAsync(d_cwdesc_.p, cw_all.data(), cw_all.size() * sizeof(CwDesc), hipMemcpyHostToDevice, st));
+            DTL_HIP_CHECK(hipMemcpyAsync(d_tbgather_.p, gathers.data(), size_t(n_tbs) * sizeof(TbGather), hipMemcpyHostToDevice, st));
             DTL_HIP_CHECK(hipMemcpyAsync(d_tbdesc_.p, tb_desc.data(), size_t(n_tbs) * sizeof(TbDesc), hipMemcpyHostToDevice, st));
+            DTL_TRY(launch_expand_cw(d_tbgather_.as<TbGather>(), n_tbs, d_cwdesc_.as<CwDesc>(), st));
             if (ev_[2]) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
             for (auto& cr : code_ranges)
                 DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
@@ -732,9 +713,7 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
             if (ev_[3]) DTL_HIP_CHECK(hipEventRecord(ev_[3], st));
             DTL_TRY(launch_tb_check(d_tbdesc_.as<TbDesc>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
                                     d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st));
-            uint64_t max_out = 0;
-            for (auto& tb : asmb.done) max_out += tb.n_bits / 8;
-            DTL_TRY(d_payload.ensure(max_out + 64));
+            DTL_TRY(d_payload.ensure(max_out_bytes + 64));
             DTL_TRY(launch_compact(d_staging_.as<uint8_t>(), stride, d_len_.as<int32_t>(), n_tbs, d_offs_.as<uint32_t>(),
                                    d_total_.as<uint32_t>(), d_payload.as<uint8_t>(), st));
             DTL_HIP_CHECK(hipMemcpyAsync(tb_res.data(), d_tbres_.p, size_t(n_tbs) * sizeof(TbResult), hipMemcpyDeviceToHost, st));
@@ -750,6 +729,8 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
         DTL_HIP_CHECK(hipMemcpyAsync(nofec_info.data(), d_nofec_info_.p, size_t(n_frames) * 8, hipMemcpyDeviceToHost, st));
         DTL_HIP_CHECK(hipMemcpyAsync(&total_bytes, d_total_.p, 4, hipMemcpyDeviceToHost, st));
     }
+    if (n_frames)
+        DTL_HIP_CHECK(hipMemcpyAsync(stats.data(), d_stats_.p, size_t(n_frames) * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
     DTL_HIP_CHECK(hipStreamSynchronize(st));
     stage_ms[6] = stage_ms[7] = 0.0;
     if (ev_[0] && n_frames) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) stage_ms[7] = ms; }

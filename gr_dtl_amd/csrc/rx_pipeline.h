@@ -123,7 +123,7 @@ private:
     int capacity_ = 0;
     std::vector<std::unique_ptr<LdpcDecoder>> decoders_; // index 0 == nullptr ("no FEC")
     DevBuf d_edges_, d_counter_, d_trig_, d_angle_, d_cands_, d_segs_, d_recs_, d_frames_, d_stats_, d_llr_off_,
-        d_cwdesc_, d_tbdesc_, d_tbres_, d_len_, d_offs_, d_total_, d_staging_, d_nofec_info_;
+        d_cwdesc_, d_tbgather_, d_tbdesc_, d_tbres_, d_len_, d_offs_, d_total_, d_staging_, d_nofec_info_;
 };
 
 } // namespace dtl

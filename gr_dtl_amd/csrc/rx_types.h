@@ -85,6 +85,20 @@ struct TbDesc {
     uint32_t n_cw;
 };
 
+// Transport block as a gather recipe: up to 4 source segments of the soft-bit stream (the receive
+// buffer of tb_decoder.cc expressed as index ranges) + the even split of the payload over n_cw
+// codewords (tb_decoder.cc:168-172).  Expanded on the device into one CwDesc per codeword.
+struct TbGather {
+    uint32_t seg_off[4];  // 0xFFFFFFFF = gap (soft bits never received)
+    int32_t seg_len[4];
+    uint32_t bits_off;    // first decoded bit of the TB in the LDPC output buffer
+    uint32_t cw_first;    // global index of the TB's first codeword
+    int32_t tb_payload;   // payload bits (user + CRC-32)
+    int16_t n_cw, n_seg;
+    int16_t ncheck, k;
+    int32_t pad;
+};
+
 struct TbResult {
     int32_t crc_ok;
     int32_t avg_it;
