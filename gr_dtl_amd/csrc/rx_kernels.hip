@@ -68,35 +68,50 @@ __device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, 
         const CfoSegment s = segs[seg];
         ph = s.phase0 + double(sens * s.angle) * double(i - s.start + 1);
     }
-    ph = fmod(ph + kPi, 2.0 * kPi);
-    if (ph < 0) ph += 2.0 * kPi;
-    ph -= kPi;
+    // wrap to [-pi, pi): ph - 2 pi floor((ph + pi) / 2 pi)
+    ph -= (2.0 * kPi) * floor((ph + kPi) * (1.0 / (2.0 * kPi)));
     return float(ph);
 }
 
-// Load OFDM symbol `sym` of the frame cut at `trigger` (delay N+cp, CP stripped, fine-CFO
-// derotated) into buf[] in bit-reversed order, then radix-2 DIT FFT in place.  blockDim.x == N.
-__device__ __forceinline__ void load_and_fft(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
-                                             int64_t trigger, int sym, const CfoSegment* segs, int n_segs,
-                                             int seg, cf32* buf)
+// Load OFDM symbols `symA` and `symB` (symB < 0: none) of the frame cut at `trigger` (delay N+cp,
+// CP stripped, fine-CFO derotated) into bufA / bufB in bit-reversed order, then radix-2 DIT FFTs in
+// place.  blockDim.x == N: the lower half of the workgroup runs the butterflies of A, the upper
+// half those of B, so every lane works in every stage.  tw: N/2 twiddles staged in LDS.
+__device__ __forceinline__ void load_and_fft2(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
+                                              int64_t trigger, int symA, int symB, const CfoSegment* segs,
+                                              int n_segs, int seg, cf32* bufA, cf32* bufB, const cf32* tw)
 {
     const int N = t.fft_len, P = N + t.cp_len;
     const int tid = threadIdx.x;
-    // mixed[i] = r[i - (N+cp)] * osc[i]; symbol sample index i = trigger + sym*P + cp + tid
-    const int64_t i = trigger + int64_t(sym) * P + t.cp_len + tid;
-    const int64_t src = i - P;
-    cf32 v = { 0.0f, 0.0f };
-    if (src >= 0 && src < n_samples) v = iq[src];
     const float sens = float(-2.0 / N);
-    const cf32 osc = expj(osc_phase(segs, n_segs, seg, i, sens));
-    buf[t.bitrev[tid]] = cmul(v, osc);
+    const int br = t.bitrev[tid];
+    {
+        // mixed[i] = r[i - (N+cp)] * osc[i]; symbol sample index i = trigger + sym*P + cp + tid
+        const int64_t i = trigger + int64_t(symA) * P + t.cp_len + tid;
+        const int64_t src = i - P;
+        cf32 v = { 0.0f, 0.0f };
+        if (src >= 0 && src < n_samples) v = iq[src];
+        bufA[br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
+    }
+    if (symB >= 0) {
+        const int64_t i = trigger + int64_t(symB) * P + t.cp_len + tid;
+        const int64_t src = i - P;
+        cf32 v = { 0.0f, 0.0f };
+        if (src >= 0 && src < n_samples) v = iq[src];
+        bufB[br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
+    }
     __syncthreads();
+    const int hN = N / 2;
+    const bool upper = tid >= hN;
+    cf32* buf = upper ? bufB : bufA;
+    const int bt = upper ? tid - hN : tid;
+    const bool active = !upper || symB >= 0;
     for (int len = 2; len <= N; len <<= 1) {
         const int half = len >> 1;
-        if (tid < N / 2) {
-            const int grp = tid / half, k = tid - grp * half;
+        if (active) {
+            const int grp = bt / half, k = bt - grp * half;
             const int a = grp * len + k, b = a + half;
-            const cf32 w = t.twiddle[k * (N / len)];
+            const cf32 w = tw[k * (N / len)];
             const cf32 u = buf[a];
             const cf32 vv = cmul(buf[b], w);
             buf[a] = cadd(u, vv);
@@ -257,11 +272,14 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     cf32* H = Y + size_t(2 + h) * N;                        // N taps (shifted positions)
     float* gabs = reinterpret_cast<float*>(H + N);          // N/2+2 |B(g)| values
     uint8_t* bits = reinterpret_cast<uint8_t*>(gabs + N / 2 + 2); // hdr_bits
+    cf32* tw = reinterpret_cast<cf32*>(bits + ((t.hdr_bits + 15) & ~15)); // N/2 twiddles
     __shared__ int s_off;
 
+    if (tid < N / 2) tw[tid] = t.twiddle[tid];
     const Candidate cd = cands[blockIdx.x];
-    for (int s = 0; s < 2 + h; s++)
-        load_and_fft(t, iq, n_samples, cd.trigger, s, segs, n_segs, cd.seg, Y + size_t(s) * N);
+    for (int s = 0; s < 2 + h; s += 2)
+        load_and_fft2(t, iq, n_samples, cd.trigger, s, (s + 1 < 2 + h) ? s + 1 : -1, segs, n_segs, cd.seg,
+                      Y + size_t(s) * N, Y + size_t(s + 1) * N, tw);
     // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N]
     auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + ((k + N / 2) & (N - 1))]; };
 
@@ -384,9 +402,11 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
 {
     extern __shared__ unsigned char smem_raw[];
     const int N = t.fft_len, L = t.frame_length, tid = threadIdx.x, h = t.header_len;
-    cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // N : FFT scratch
-    cf32* frame = buf + N;                            // L x N : shifted/derotated FFT output -> soft symbols
+    cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // 2 x N : FFT scratch (two symbols per pass)
+    cf32* frame = buf + 2 * N;                        // L x N : shifted/derotated FFT output -> soft symbols
     Welford* wred = reinterpret_cast<Welford*>(frame + size_t(L) * N); // blockDim/64 partials
+    cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64);          // N/2 twiddles
+    if (tid < N / 2) tw[tid] = t.twiddle[tid];
     __shared__ FrameStat s_stat;
 
     const FrameDesc fd = frames[blockIdx.x];
@@ -396,15 +416,21 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
     // zero fill of the integer-CFO shift (:154-166)
     if (off < 0) { for (int p = tid; p < -off; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
     else { for (int p = total - off + tid; p < total; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
-    for (int i = 0; i < L; i++) {
-        load_and_fft(t, iq, n_samples, fd.trigger, 2 + h + i, segs, n_segs, fd.seg, buf);
+    for (int i0 = 0; i0 < L; i0 += 2) {
+        const bool two = i0 + 1 < L;
+        load_and_fft2(t, iq, n_samples, fd.trigger, 2 + h + i0, two ? 2 + h + i0 + 1 : -1, segs, n_segs, fd.seg,
+                      buf, buf + N, tw);
         // out[p - off] = in[p], then out *= expj(-2 pi off cp / N (sym+1)) with sym of the destination
-        const int p = i * N + tid;
-        const int dst = p - off;
-        if (dst >= 0 && dst < total) {
-            const cf32 v = buf[(tid + N / 2) & (N - 1)];
-            const float ph = float(-(2.0 * kPi) * off * t.cp_len / N * (dst / N + 1));
-            frame[dst] = cmul(v, expj(ph));
+        for (int u = 0; u < (two ? 2 : 1); u++) {
+            const int p = (i0 + u) * N + tid;
+            const int dst = p - off;
+            if (dst >= 0 && dst < total) {
+                const cf32 v = buf[u * N + ((tid + N / 2) & (N - 1))];
+                cf32 pc = { 1.0f, 0.0f };
+                if (off != 0) pc = expj(float(-(2.0 * kPi) * off * t.cp_len / N * (dst / N + 1)));
+                else pc = { 1.0f, -0.0f }; // expj(-0.0f): cos = 1, sin = -0
+                frame[dst] = cmul(v, pc);
+            }
         }
         __syncthreads();
     }
@@ -565,29 +591,59 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
                                                      uint8_t* __restrict__ staging, int stride,
                                                      TbResult* __restrict__ res)
 {
+    // LDS: 4 x 256-entry CRC-32 tables (slicing-by-4, reflected polynomial 0xEDB88320 == the
+    // reference's crc(32, 0x04C11DB7, ~0, ~0, refin, refout)) + the TB's packed bytes
+    extern __shared__ uint32_t tb_smem[];
+    uint32_t* T = tb_smem;                                   // T[k*256 + i]
+    uint8_t* bytes_l = reinterpret_cast<uint8_t*>(tb_smem + 1024);
     const int tb = blockIdx.x;
     if (tb >= n_tbs) return;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = uint32_t(i);
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+        T[i] = c;
+    }
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = T[i];
+        for (int k = 1; k < 4; k++) {
+            c = T[c & 0xFF] ^ (c >> 8);
+            T[k * 256 + i] = c;
+        }
+    }
     const TbDesc d = tbs[tb];
     uint8_t* bytes = staging + size_t(tb) * stride;
     const int n_bytes = int(d.n_bits / 8);
-    for (int b = threadIdx.x; b < n_bytes; b += 64) {
+    for (int b = lane; b < n_bytes; b += 64) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(bits + size_t(d.bits_off) + size_t(b) * 8);
         unsigned v = 0;
-        for (int j = 0; j < 8; j++) v |= unsigned(bits[size_t(d.bits_off) + b * 8 + j] & 1) << j;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v |= unsigned((w >> (8 * j)) & 1ull) << j;   // repack(1,8) LSB first
+        bytes_l[b] = uint8_t(v);
         bytes[b] = uint8_t(v);
     }
     int it_sum = 0;
-    for (unsigned c = threadIdx.x; c < d.n_cw; c += 64) it_sum += nit[d.cw_first + c];
+    for (unsigned c = lane; c < d.n_cw; c += 64) it_sum += nit[d.cw_first + c];
     for (int o = 32; o > 0; o >>= 1) it_sum += __shfl_down(it_sum, o);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         TbResult r{};
         r.user_bits = int(d.n_bits) - 32;
         r.avg_it = d.n_cw ? it_sum / int(d.n_cw) : 0;
         int ok = 0;
         if (n_bytes >= 4) {
-            const uint32_t crc = crc_bits(bytes, n_bytes - 4, 32, 0x04C11DB7u, 0xFFFFFFFFu, 0xFFFFFFFFu, true, true);
+            const int len = n_bytes - 4;
+            uint32_t crc = 0xFFFFFFFFu;
+            int i = 0;
+            for (; i + 4 <= len; i += 4) {
+                crc ^= uint32_t(bytes_l[i]) | (uint32_t(bytes_l[i + 1]) << 8) | (uint32_t(bytes_l[i + 2]) << 16) | (uint32_t(bytes_l[i + 3]) << 24);
+                crc = T[3 * 256 + (crc & 0xFF)] ^ T[2 * 256 + ((crc >> 8) & 0xFF)] ^ T[256 + ((crc >> 16) & 0xFF)] ^ T[crc >> 24];
+            }
+            for (; i < len; i++) crc = T[(crc ^ bytes_l[i]) & 0xFF] ^ (crc >> 8);
+            crc = ~crc;
             ok = 1;
-            for (int i = 0; i < 4; i++) if (bytes[n_bytes - 4 + i] != ((crc >> (8 * i)) & 0xFF)) ok = 0;
+            for (int k = 0; k < 4; k++) if (bytes_l[len + k] != ((crc >> (8 * k)) & 0xFF)) ok = 0;
         }
         r.crc_ok = ok;
         res[tb] = r;
@@ -709,8 +765,9 @@ int launch_trigger_angle(const cf32* iq, int64_t n, int N, const int64_t* trig, 
 
 size_t header_lds_bytes(const RxTables& t)
 {
-    size_t b = size_t(2 + t.header_len) * t.fft_len * sizeof(cf32) + size_t(t.fft_len) * sizeof(cf32) +
-               size_t(t.fft_len / 2 + 2) * sizeof(float) + size_t(t.hdr_bits);
+    size_t b = size_t(2 + t.header_len + 1) * t.fft_len * sizeof(cf32) + size_t(t.fft_len) * sizeof(cf32) +
+               size_t(t.fft_len / 2 + 2) * sizeof(float) + size_t((t.hdr_bits + 15) & ~15) +
+               size_t(t.fft_len / 2) * sizeof(cf32);
     return (b + 15) & ~size_t(15);
 }
 
@@ -727,8 +784,8 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
 
 size_t payload_lds_bytes(const RxTables& t)
 {
-    size_t b = size_t(t.fft_len) * sizeof(cf32) + size_t(t.frame_length) * t.fft_len * sizeof(cf32) +
-               size_t((t.fft_len + 63) / 64) * sizeof(Welford);
+    size_t b = size_t(2 * t.fft_len) * sizeof(cf32) + size_t(t.frame_length) * t.fft_len * sizeof(cf32) +
+               size_t((t.fft_len + 63) / 64) * sizeof(Welford) + size_t(t.fft_len / 2) * sizeof(cf32);
     return (b + 15) & ~size_t(15);
 }
 
@@ -757,7 +814,9 @@ int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int
                     int stride, TbResult* res, int32_t* len, hipStream_t st)
 {
     if (n_tbs <= 0) return DTL_OK;
-    hipLaunchKernelGGL(tb_check_kernel, dim3(n_tbs), dim3(64), 0, st, tbs, n_tbs, bits, nit, staging, stride, res);
+    const size_t lds = 4096 + size_t((stride + 15) & ~15);
+    if (lds > 64 * 1024) { set_last_error("tb_check: transport block too large"); return DTL_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(tb_check_kernel, dim3(n_tbs), dim3(64), lds, st, tbs, n_tbs, bits, nit, staging, stride, res);
     hipLaunchKernelGGL(tb_lengths_kernel, dim3((n_tbs + 255) / 256), dim3(256), 0, st, res, n_tbs, len);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;

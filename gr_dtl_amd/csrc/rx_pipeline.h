@@ -91,6 +91,15 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// page-locked host staging (async copies from/to pageable memory make the runtime pin pages per copy)
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~HostBuf();
+    int ensure(size_t bytes);
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 class Receiver {
 public:
     RxConfig cfg;
@@ -108,6 +117,7 @@ public:
     int64_t n_llr = 0;
     int64_t n_codewords = 0;
     double stage_ms[8] = { 0 };
+    double dbg_plateau_ms = 0;
     DevBuf d_payload, d_eq_hard, d_eq_soft, d_soft_syms, d_llr, d_taps, d_hdr_bits, d_metric, d_cw_bits, d_cw_nit;
 
     int frame_capacity() const { return capacity_; }
@@ -124,6 +134,8 @@ private:
     std::vector<std::unique_ptr<LdpcDecoder>> decoders_; // index 0 == nullptr ("no FEC")
     DevBuf d_edges_, d_counter_, d_trig_, d_angle_, d_cands_, d_segs_, d_recs_, d_frames_, d_stats_, d_llr_off_,
         d_cwdesc_, d_tbgather_, d_tbdesc_, d_tbres_, d_len_, d_offs_, d_total_, d_staging_, d_nofec_info_;
+    HostBuf h_small_, h_edges_, h_trig_, h_angle_, h_cands_, h_segs_, h_recs_, h_frames_, h_llr_off_, h_gather_,
+        h_tbdesc_, h_stats_, h_tbres_, h_nofec_;
 };
 
 } // namespace dtl
