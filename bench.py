@@ -143,19 +143,19 @@ def main():
         stage += np.array(res.stage_ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    tot = torch.tensor([float(n_samples), float(res.n_payload_bytes), float(res.n_payload_frames),
-                        float(res.n_codewords)], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)   # tiny result gather (counts only); no data-path collective
-    elapsed = float(t.item())
-    total_samples = float(tot[0].item())
+    from gr_dtl_amd.sharding import combine
+    # max-over-ranks time, summed counters (two tiny all-reduces; no data-path collective)
+    elapsed, tot = combine(elapsed, [n_samples, res.n_payload_bytes, res.n_payload_frames, res.n_codewords],
+                           dist, device)
+    total_samples = float(tot[0])
     ms_per_step = elapsed / args.steps * 1e3
     value = total_samples * args.steps / elapsed / 1e6
 
     out = None
     if rank == 0:
+        extra = rx.work(x, want=("cw",))                      # untimed: per-codeword iteration counts
+        cw_it = float(extra.cw_nit.float().mean().item()) if extra.cw_nit is not None else 0.0
+        cw_max = float((extra.cw_nit == 15).float().mean().item()) if extra.cw_nit is not None else 0.0
         ok_tbs = int((res.tbs["crc_ok"] == 1).sum())
         avg_it = float(res.tbs["avg_it"].mean()) if len(res.tbs) else 0.0
         t_ldpc = float(np.mean(ldpc_ms)) if ldpc_ms else 0.0
@@ -177,14 +177,15 @@ def main():
                        "samples_per_gpu": n_samples, "constellation": int(w["cnst"]), "esn0_db": w["esn0_db"],
                        "sync_threshold": w["sync_threshold"], "ldpc": "n=300 k=152, <=15 it, f64 LR-domain SPA",
                        "parallelism": "frame-batch shard per GPU (dp%d), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "ldpc_bp_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "ldpc_bp_np_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "kernel_ms": round(t_ldpc, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "kernel is FP64-VALU/LDS bound (4 f64 divisions per Tanner edge per iteration), "
                                  "not HBM bound; see DESIGN.md"},
             "stats": {"frames_decoded": int(res.n_payload_frames), "tbs": int(len(res.tbs)), "tbs_crc_ok": ok_tbs,
-                      "avg_bp_iterations": round(avg_it, 3), "codewords": int(res.n_codewords),
+                      "avg_bp_iterations_per_tb": round(avg_it, 3), "bp_iterations_per_codeword": round(cw_it, 3),
+                      "codewords_at_max_iterations": round(cw_max, 4), "codewords": int(res.n_codewords),
                       "payload_bytes": int(res.n_payload_bytes), "user_bytes_sent": int(n_user),
                       "payload_kernel_ms": round(float(np.mean(payload_ms)), 3),
                       "host_stage_ms": [round(float(s) / args.steps, 3) for s in stage[:6]],

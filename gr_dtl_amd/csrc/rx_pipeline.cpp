@@ -555,7 +555,7 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     lap("edges d2h");
     const double t_e = now_ms();
     raw_triggers = plateau_from_edges(std::move(edges), n, cp);
-    stage_ms[5] = double(n_edges);          // diagnostics: threshold crossings in this batch
+    dbg_n_edges = n_edges;
     stage_ms[0] = now_ms() - t0; t0 = now_ms();
     dbg_plateau_ms = t0 - t_e;
 
@@ -910,8 +910,8 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
             tbs.push_back(ti);
         }
     }
-    stage_ms[1] += 0.0;
-    stage_ms[2] += 0.0; if (getenv("DTL_DEBUG")) fprintf(stderr, "n_edges=%.0f plateau_ms=%.3f\n", stage_ms[5], dbg_plateau_ms);
+    stage_ms[5] = now_ms() - t0;
+    if (dbg) fprintf(stderr, "  [n_edges=%u plateau %.3f ms]\n", dbg_n_edges, dbg_plateau_ms);
     return DTL_OK;
 }
 

@@ -118,6 +118,7 @@ public:
     int64_t n_codewords = 0;
     double stage_ms[8] = { 0 };
     double dbg_plateau_ms = 0;
+    unsigned dbg_n_edges = 0;
     DevBuf d_payload, d_eq_hard, d_eq_soft, d_soft_syms, d_llr, d_taps, d_hdr_bits, d_metric, d_cw_bits, d_cw_nit;
 
     int frame_capacity() const { return capacity_; }
