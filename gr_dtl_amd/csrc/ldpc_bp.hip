@@ -162,7 +162,7 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int MAXR, int MAXC>
+template <int MAXR, int MAXC, int NV>
 __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables t, NpShared sh,
                                                                      const uint16_t* __restrict__ col_ptr_g,
                                                                      const uint16_t* __restrict__ perm_g,
@@ -206,28 +206,51 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         return __ballot(bad != 0) == 0ull;
     };
 
-    for (int cw = blockIdx.x * kNpWaves + wave; cw < ncw; cw += gridDim.x * kNpWaves) {
-        uint32_t off0, off1, out_off;
-        int len0, k_used;
+    // soft bits of one codeword in on-air order, lane l holds positions l, l+64, ... (coalesced);
+    // the NEXT codeword's soft bits are fetched before the current one is decoded so that the HBM
+    // latency hides behind the belief propagation (or behind the previous codeword's syndrome).
+    struct Meta { uint32_t out_off; int k_used; };
+    auto fetch = [&](int cw, float (&vals)[NV], Meta& m) {
+        uint32_t off0, off1;
+        int len0;
         if (desc) {
             const CwDesc d = desc[cw];
-            off0 = d.llr_off0; off1 = d.llr_off1; out_off = d.out_off; len0 = d.len0; k_used = d.k_used;
+            off0 = d.llr_off0; off1 = d.llr_off1; m.out_off = d.out_off; len0 = d.len0; m.k_used = d.k_used;
         } else {
-            off0 = uint32_t(cw) * uint32_t(t.n); off1 = 0; out_off = uint32_t(cw) * uint32_t(t.k);
-            len0 = t.n; k_used = t.k;
+            off0 = uint32_t(cw) * uint32_t(t.n); off1 = 0; m.out_off = uint32_t(cw) * uint32_t(t.k);
+            len0 = t.n; m.k_used = t.k;
         }
-        const int n_sent = ncheck + k_used;
-        // coalesced read in on-air order, scattered to y[permute[i]] = -llr[i] (ldpc_dec.cc:64-66)
-        for (int i = lane; i < t.n; i += kWave) {
-            float val = kShortenedValue;
-            if (i < n_sent) {
+        const int n_sent = ncheck + m.k_used;
+#pragma unroll
+        for (int p = 0; p < NV; p++) {
+            const int i = lane + p * kWave;
+            float val = kShortenedValue; // never-sent (shortened) positions, tb_decoder.cc:163-183
+            if (i < t.n && i < n_sent) {
                 if (i < len0) val = llr[size_t(off0) + i];
                 else val = (off1 != 0xFFFFFFFFu) ? llr[size_t(off1) + (i - len0)] : 0.0f;
             }
-            const float y = -1 * val;
-            const int v = perm[i];
-            ybuf[v] = y;
-            est[v] = (y < 0) ? 1 : 0;
+            vals[p] = val;
+        }
+    };
+    const int stride = gridDim.x * kNpWaves;
+    float cur[NV], nxt[NV];
+    Meta mcur{ 0, 0 }, mnxt{ 0, 0 };
+    int cw = blockIdx.x * kNpWaves + wave;
+    if (cw < ncw) fetch(cw, cur, mcur);
+    for (; cw < ncw; cw += stride) {
+        if (cw + stride < ncw) fetch(cw + stride, nxt, mnxt);
+        const uint32_t out_off = mcur.out_off;
+        const int k_used = mcur.k_used;
+        // scatter to y[permute[i]] = -llr[i] (ldpc_dec.cc:64-66)
+#pragma unroll
+        for (int p = 0; p < NV; p++) {
+            const int i = lane + p * kWave;
+            if (i < t.n) {
+                const float y = -1 * cur[p];
+                const int v = perm[i];
+                ybuf[v] = y;
+                est[v] = (y < 0) ? 1 : 0;
+            }
         }
         wave_sync();
         int nit = 0;
@@ -283,6 +306,9 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         for (int i = lane; i < k_used; i += kWave) out_bits[size_t(out_off) + i] = est[sys_src[i]];
         if (lane == 0) out_nit[cw] = nit;
         wave_sync(); // the wave's LDS slice is reused by its next codeword
+#pragma unroll
+        for (int p = 0; p < NV; p++) cur[p] = nxt[p];
+        mcur = mnxt;
     }
 }
 
@@ -353,9 +379,9 @@ int LdpcDecoder::upload()
         np_sh_.wave_base = int(off);
         np_sh_.wave_stride = int(al(lds_bytes()));
         np_lds_ = off + size_t(kNpWaves) * np_sh_.wave_stride;
-        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && np_lds_ <= 160 * 1024;
+        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && np_lds_ <= 160 * 1024;
         if (np_ok_) {
-            for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3>), reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4>) })
+            for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5>), reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8>) })
                 DTL_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(np_lds_)));
         }
     }
@@ -375,7 +401,8 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
     }
     if (np_ok_) {
         const int grid = int(std::min<size_t>((ncw + kNpWaves - 1) / kNpWaves, 256));
-        auto kern = (code.max_row_deg <= 6 && code.max_col_deg <= 3) ? ldpc_bp_np_kernel<6, 3> : ldpc_bp_np_kernel<8, 4>;
+        auto kern = (code.max_row_deg <= 6 && code.max_col_deg <= 3 && code.n <= 320) ? ldpc_bp_np_kernel<6, 3, 5>
+                                                                                         : ldpc_bp_np_kernel<8, 4, 8>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_col_ptr_, np_perm_,
                            d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit);
         DTL_HIP_CHECK(hipGetLastError());
