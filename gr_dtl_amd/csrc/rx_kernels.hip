@@ -271,7 +271,8 @@ __global__ __launch_bounds__(64) void trigger_angle_kernel(const cf32* __restric
         pr += __shfl_down(pr, off);
         pi += __shfl_down(pi, off);
     }
-    if (threadIdx.x == 0) angle[w] = atan2f(float(-pi), float(-pr));
+    // atan2 in double, rounded to float once (same definition as the CPU chain; libm-independent)
+    if (threadIdx.x == 0) angle[w] = float(atan2(double(float(-pi)), double(float(-pr))));
 }
 
 // ------------------------------------------------------------------------------------------

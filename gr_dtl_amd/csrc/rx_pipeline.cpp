@@ -512,7 +512,12 @@ int Receiver::upload_tables()
 
 int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t st)
 {
-    if (!d_iq || n < 0) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
+    if (n < 0 || (!d_iq && n > 0)) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
+    if (n == 0) { // an empty work() call: nothing consumed, nothing produced
+        frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
+        n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
+        return DTL_OK;
+    }
     if (n > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
     if (!uploaded_) DTL_TRY(upload_tables());
     if (!ev_[0]) for (auto& e : ev_) DTL_HIP_CHECK(hipEventCreate(&e));

@@ -156,7 +156,9 @@ void orc_sync_sc(const orc_cfg* cfg, const orc_c32* iq, long n, float* metric_ou
         float Pr = (float)(-pr), Pi = (float)(-pi), E = (float)en;
         float num = Pr * Pr + Pi * Pi;
         metric[i] = num / (E * E);
-        arg[i] = atan2f(Pi, Pr);
+        /* complex_to_arg: the reference uses a table/polynomial atan2 approximation (1e-4 rad);
+         * restated as the correctly rounded value: atan2 in double, rounded to float once */
+        arg[i] = (float)atan2((double)Pi, (double)Pr);
     }
     /* plateau_detector_fb(max_len = cp_len, threshold), unbounded-buffer form */
     memset(trig, 0, n);

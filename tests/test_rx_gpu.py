@@ -128,3 +128,69 @@ def test_fec_chain_matches_oracle_large_fft(oracle, dtl, cuda, fft_len, frame_le
     rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
     assert ref["n_frames"] > 0.5 * len(hdrs)
     _compare(rx, res, ref, ocfg, True)
+
+
+def _apply_cfo(x, eps_subcarriers, fft_len):
+    n = np.arange(x.size, dtype=np.float64)
+    return (x * np.exp(2j * np.pi * eps_subcarriers * n / fft_len)).astype(np.complex64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eps", [0.21, -0.37, 2.0, -2.3, 4.18])
+def test_carrier_frequency_offset_matches_oracle(oracle, dtl, cuda, eps):
+    """Fine CFO (Schmidl-Cox angle -> oscillator) and integer CFO (ofdm_chanest_vcvc carrier offset ->
+    frame_equalizer shift + per-symbol phase) paths: frequency offsets of a fraction / several subcarriers."""
+    pcfg, ocfg, code = make_pair(oracle, dtl)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 2, 5000, None, seed=31)
+    x = _apply_cfo(x, eps, 64)
+    rng = np.random.default_rng(5)
+    nv = 64 * 0.25 / 10 ** (16.0 / 10)
+    x = (x + (rng.normal(0, np.sqrt(nv / 2), x.size) + 1j * rng.normal(0, np.sqrt(nv / 2), x.size))).astype(np.complex64)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
+    assert ref["n_frames"] >= 0.8 * len(hdrs)
+    offs = {f["carr_offset"] for f in ref["frames"] if f["header_ok"]}
+    if abs(eps) >= 1.5:
+        assert offs and 0 not in offs, "test must exercise a non-zero integer carrier offset"
+    _compare(rx, res, ref, ocfg, True)
+    good = sum(t["crc_ok"] for t in ref["tbs"])
+    assert good >= 0.7 * len(ref["tbs"])
+
+
+@pytest.mark.gpu
+def test_mixed_mcs_stream_matches_oracle(oracle, dtl, cuda):
+    """config #5 style: the constellation changes from segment to segment inside one batch (BPSK..16-QAM)."""
+    pcfg, ocfg, code = make_pair(oracle, dtl)
+    rng = np.random.default_rng(77)
+    parts = []
+    frame_no = 0
+    for cnst in (1, 2, 3, 4, 2, 4, 1, 3):
+        user = rng.integers(0, 256, 700 * cnst).astype(np.uint8)
+        syms, hdrs = oracle.fec_frames_build(code, 1, cnst, ocfg.frame_capacity, user, first_frame_no=frame_no)
+        frame_no += len(hdrs)
+        parts.append(oracle.tx_frames(ocfg, syms, hdrs).reshape(-1))
+    x = np.concatenate([np.zeros(100, np.complex64)] + parts + [np.zeros(ocfg.frame_samples, np.complex64)])
+    nv = 64 / 10 ** (26.0 / 10)
+    x = (x + (rng.normal(0, np.sqrt(nv / 2), x.size) + 1j * rng.normal(0, np.sqrt(nv / 2), x.size))).astype(np.complex64)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
+    assert {f["hdr"]["cnst"] for f in ref["frames"] if f["header_ok"]} == {1, 2, 3, 4}
+    _compare(rx, res, ref, ocfg, True)
+
+
+@pytest.mark.gpu
+def test_degenerate_inputs(oracle, dtl, cuda):
+    """empty stream, pure noise (no trigger), a stream that ends in the middle of a frame."""
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl)
+    rx = dtl.ofdm_receiver(pcfg)
+    res = rx.work(torch.zeros(0, dtype=torch.complex64, device=cuda))
+    assert len(res.frames) == 0 and res.payload.numel() == 0
+    rng = np.random.default_rng(1)
+    noise = (rng.normal(0, 1, 50000) + 1j * rng.normal(0, 1, 50000)).astype(np.complex64)
+    res = rx.work(torch.from_numpy(noise).to(cuda))
+    ref = oracle.rx_stream(ocfg, code, noise, want=("frames", "trig"))
+    np.testing.assert_array_equal(res.raw_triggers, np.nonzero(ref["trig_raw"])[0])
+    assert len(res.frames) == ref["n_frames"]
+    user, hdrs, x = make_stream(oracle, ocfg, code, 2, 3000, 14.0, seed=3)
+    x = x[:100 + 5 * ocfg.frame_samples + 700]
+    rx2, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
+    _compare(rx2, res, ref, ocfg, True)
