@@ -37,7 +37,7 @@ _vp = C.c_void_p
 
 class CwDesc(C.Structure):
     _fields_ = [("llr_off0", C.c_uint32), ("llr_off1", C.c_uint32), ("out_off", C.c_uint32),
-                ("len0", C.c_uint16), ("k_used", C.c_uint16)]
+                ("len0", C.c_uint16), ("len1", C.c_uint16), ("k_used", C.c_uint16), ("pad", C.c_uint16)]
 
 
 def lib():

@@ -12,8 +12,10 @@ struct CwDesc {
     uint32_t llr_off0;  // first on-air soft bit (offset into the LLR stream)
     uint32_t llr_off1;  // continuation when the codeword straddles two frames
     uint32_t out_off;   // first decoded bit (1 bit per byte) in the output buffer
-    uint16_t len0;      // soft bits taken from llr_off0 (rest from llr_off1)
+    uint16_t len0;      // soft bits taken from llr_off0
+    uint16_t len1;      // soft bits taken from llr_off1; sent positions beyond len0+len1 were never received (0)
     uint16_t k_used;    // systematic bits actually sent (k minus shortening)
+    uint16_t pad;
 };
 
 struct LdpcTables {

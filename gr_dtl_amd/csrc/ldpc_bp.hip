@@ -59,13 +59,13 @@ __global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const floa
 
     for (int cw = blockIdx.x; cw < ncw; cw += gridDim.x) {
         uint32_t off0, off1, out_off;
-        int len0, k_used;
+        int len0, len1, k_used;
         if (desc) {
             CwDesc d = desc[cw];
-            off0 = d.llr_off0; off1 = d.llr_off1; out_off = d.out_off; len0 = d.len0; k_used = d.k_used;
+            off0 = d.llr_off0; off1 = d.llr_off1; out_off = d.out_off; len0 = d.len0; len1 = d.len1; k_used = d.k_used;
         } else {
             off0 = uint32_t(cw) * uint32_t(t.n); off1 = 0; out_off = uint32_t(cw) * uint32_t(t.k);
-            len0 = t.n; k_used = t.k;
+            len0 = t.n; len1 = 0; k_used = t.k;
         }
         const int n_sent = ncheck + k_used;
 
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const floa
             float val = kShortenedValue;
             if (src < n_sent) {
                 if (src < len0) val = llr[size_t(off0) + src];
-                else val = (off1 != 0xFFFFFFFFu) ? llr[size_t(off1) + (src - len0)] : 0.0f; // soft bit never received
+                else val = (src < len0 + len1) ? llr[size_t(off1) + (src - len0)] : 0.0f; // else: never received
             }
             const float y = -1 * val;
             ybuf[v] = y;
@@ -212,13 +212,13 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     struct Meta { uint32_t out_off; int k_used; };
     auto fetch = [&](int cw, float (&vals)[NV], Meta& m) {
         uint32_t off0, off1;
-        int len0;
+        int len0, len1;
         if (desc) {
             const CwDesc d = desc[cw];
-            off0 = d.llr_off0; off1 = d.llr_off1; m.out_off = d.out_off; len0 = d.len0; m.k_used = d.k_used;
+            off0 = d.llr_off0; off1 = d.llr_off1; m.out_off = d.out_off; len0 = d.len0; len1 = d.len1; m.k_used = d.k_used;
         } else {
             off0 = uint32_t(cw) * uint32_t(t.n); off1 = 0; m.out_off = uint32_t(cw) * uint32_t(t.k);
-            len0 = t.n; m.k_used = t.k;
+            len0 = t.n; len1 = 0; m.k_used = t.k;
         }
         const int n_sent = ncheck + m.k_used;
 #pragma unroll
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             float val = kShortenedValue; // never-sent (shortened) positions, tb_decoder.cc:163-183
             if (i < t.n && i < n_sent) {
                 if (i < len0) val = llr[size_t(off0) + i];
-                else val = (off1 != 0xFFFFFFFFu) ? llr[size_t(off1) + (i - len0)] : 0.0f;
+                else val = (i < len0 + len1) ? llr[size_t(off1) + (i - len0)] : 0.0f; // else: never received
             }
             vals[p] = val;
         }

@@ -12,6 +12,8 @@
 // std::complex<float> code on x86-64.
 #include "rx_kernels.h"
 
+#include "dtl_math.h"
+
 #pragma clang fp contract(off)
 
 namespace dtl {
@@ -50,29 +52,11 @@ __device__ __forceinline__ cf32 cdiv(cf32 x, cf32 y)
 __device__ __forceinline__ cf32 expj(float phase)
 {
     float s, c;
-    sincosf(phase, &s, &c);
+    dm_sincos(phase, &s, &c);
     return { c, s };
 }
 
 constexpr double kPi = 3.14159265358979323846;
-
-// exp / log through the hardware base-2 units (v_exp_f32 / v_log_f32, 1 ulp) with explicit scaling
-// so that subnormal results / arguments keep their value (the demapper's probabilities reach 1e-40
-// at high SNR and the reference's expf/logf do not flush them).
-__device__ __forceinline__ float fast_exp(float x)
-{
-    const float y = x * 1.44269504088896341f;
-    const bool small = y < -126.0f;
-    const float r = __builtin_amdgcn_exp2f(small ? y + 32.0f : y);
-    return small ? r * 0x1p-32f : r;
-}
-__device__ __forceinline__ float fast_log(float p)
-{
-    const bool small = p < 0x1p-100f;
-    float l = __builtin_amdgcn_logf(small ? p * 0x1p64f : p);
-    if (small) l -= 64.0f;
-    return l * 0.693147180559945309f;
-}
 
 // Oscillator phase at stream index i: frequency_modulator_fc(-2/N) integrating the held angle.
 __device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, int n_segs, int seg,
@@ -311,7 +295,7 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
             const cf32 cv = t.corr_v[k];
             if (cnonzero(cv)) acc = cadd(acc, cmul(cmul(cconj(ysh(0, k + g)), cconj(cv)), ysh(1, k + g)));
         }
-        gabs[gi] = hypotf(acc.re, acc.im);
+        gabs[gi] = sqrtf(acc.re * acc.re + acc.im * acc.im);
     }
     __syncthreads();
     if (tid == 0) {
@@ -447,7 +431,7 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
                 const cf32 v = buf[u * N + ((tid + N / 2) & (N - 1))];
                 cf32 pc = { 1.0f, 0.0f };
                 if (off != 0) pc = expj(float(-(2.0 * kPi) * off * t.cp_len / N * (dst / N + 1)));
-                else pc = { 1.0f, -0.0f }; // expj(-0.0f): cos = 1, sin = -0
+                else pc = expj(-0.0f);
                 frame[dst] = cmul(v, pc);
             }
         }
@@ -473,7 +457,7 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
             const cf32 pv = t.pilot_val[pset * N + k];
             const cf32 pilot_eq = cdiv(y, Hk);
             // mpsk_snr_est_simple::update on |pilot_eq| (Welford, double)
-            const double x = double(hypotf(pilot_eq.re, pilot_eq.im));
+            const double x = double(sqrtf(pilot_eq.re * pilot_eq.re + pilot_eq.im * pilot_eq.im));
             w.n += 1.0;
             const double d = x - w.mean;
             w.mean += d / w.n;
@@ -540,10 +524,8 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
                 float p0[kMaxBps] = { 0, 0, 0, 0 }, p1[kMaxBps] = { 0, 0, 0, 0 };
                 for (int m = 0; m < M; m++) {
                     const float dr = s.re - pts[m].re, di = s.im - pts[m].im;
-                    const float dist = t.llr_dist_mode ? hypotf(dr, di) : (dr * dr + di * di);
-                    // d = exp(-dist/npwr) through the hardware exp2 (v_exp_f32, 1 ulp): |error| <= ~2e-6
-                    // relative for the exponents seen here, far inside the 1e-5 soft-bit tolerance
-                    const float d = fast_exp(-dist / npwr);
+                    const float dist = t.llr_dist_mode ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
+                    const float d = dm_exp(-dist / npwr); // fixed-sequence expf (dtl_math.h)
 #pragma unroll
                     for (int j = 0; j < kMaxBps; j++) {
                         if (j < bps) { if ((m >> j) & 1) p1[j] += d; else p0[j] += d; }
@@ -552,7 +534,7 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
                 float* o = llr_out + size_t(llr_off[blockIdx.x]) + size_t(q) * bps;
 #pragma unroll
                 for (int j = 0; j < kMaxBps; j++)
-                    if (j < bps) o[j] = fast_log(p1[j]) - fast_log(p0[j]);
+                    if (j < bps) o[j] = dm_log(p1[j]) - dm_log(p0[j]);
             }
         }
         q_base += nocc;
@@ -690,19 +672,23 @@ __global__ __launch_bounds__(64) void expand_cw_kernel(const TbGather* __restric
         CwDesc d;
         d.out_off = g.bits_off + uint32_t(before);
         d.k_used = uint16_t(k_used);
+        d.len1 = 0; d.pad = 0; d.llr_off1 = 0;
         int si = 0;
         long seg_start = 0;
         while (si < g.n_seg && seg_start + g.seg_len[si] <= rcv_idx) { seg_start += g.seg_len[si]; si++; }
         if (si >= g.n_seg || g.seg_off[si] == 0xFFFFFFFFu) {
-            d.llr_off0 = 0; d.len0 = 0; d.llr_off1 = 0xFFFFFFFFu;
+            d.llr_off0 = 0; d.len0 = 0; // nothing (or a gap) at the codeword's start: never received
         } else {
             const long in_seg = rcv_idx - seg_start;
             const long avail0 = g.seg_len[si] - in_seg;
             d.llr_off0 = g.seg_off[si] + uint32_t(in_seg);
-            if (avail0 >= want) { d.len0 = uint16_t(want); d.llr_off1 = 0xFFFFFFFFu; }
+            if (avail0 >= want) d.len0 = uint16_t(want);
             else {
                 d.len0 = uint16_t(avail0);
-                d.llr_off1 = (si + 1 < g.n_seg) ? g.seg_off[si + 1] : 0xFFFFFFFFu;
+                if (si + 1 < g.n_seg && g.seg_off[si + 1] != 0xFFFFFFFFu) {
+                    d.llr_off1 = g.seg_off[si + 1];
+                    d.len1 = uint16_t(min(long(g.seg_len[si + 1]), want - avail0));
+                }
             }
         }
         out[g.cw_first + i] = d;

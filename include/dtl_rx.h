@@ -71,11 +71,12 @@ int dtl_ldpc_decode_batch(const dtl_ldpc* h, const float* d_llr, size_t ncw, uin
                           int32_t* d_nit, void* stream);
 
 /* Gather-table form used by the transport-block path (tb_decoder::decode): codeword i takes
- * len0 soft bits at llr_off0 then the rest at llr_off1, is padded with the shortening value
- * -15 beyond (n-k)+k_used, and writes k_used decoded bits at out_off. */
+ * len0 soft bits at llr_off0 then len1 at llr_off1; sent positions beyond len0+len1 were never
+ * received (soft value 0); positions beyond (n-k)+k_used are shortened (-15); k_used decoded bits
+ * are written at out_off. */
 typedef struct dtl_cw_desc {
     uint32_t llr_off0, llr_off1, out_off;
-    uint16_t len0, k_used;
+    uint16_t len0, len1, k_used, pad;
 } dtl_cw_desc;
 int dtl_ldpc_decode_gather(const dtl_ldpc* h, const float* d_llr, const dtl_cw_desc* d_desc,
                            size_t ncw, uint8_t* d_bits, int32_t* d_nit, void* stream);

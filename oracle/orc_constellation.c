@@ -14,6 +14,8 @@
 
 #include <math.h>
 
+#include "orc_math.h"
+
 int orc_bits_per_symbol(int cnst)
 {
     switch (cnst) {
@@ -99,14 +101,14 @@ void orc_calc_soft_dec(int cnst, orc_c32 sample, float npwr, int dist_mode, floa
     float tmp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     for (int i = 0; i < M; i++) {
         float dr = sample.re - pts[i].re, di = sample.im - pts[i].im;
-        float dist = dist_mode ? hypotf(dr, di) : (dr * dr + di * di);
-        float d = expf(-dist / npwr);
+        float dist = dist_mode ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
+        float d = orc_expf(-dist / npwr); /* expf with a fixed operation sequence, orc_math.h */
         for (int j = 0; j < k; j++) {
             int bit = (i >> j) & 1;
             tmp[2 * j + bit] += d;
         }
     }
-    for (int i = 0; i < k; i++) out[k - 1 - i] = logf(tmp[2 * i + 1]) - logf(tmp[2 * i + 0]);
+    for (int i = 0; i < k; i++) out[k - 1 - i] = orc_logf(tmp[2 * i + 1]) - orc_logf(tmp[2 * i + 0]);
 }
 
 /* lib/dtl/ofdm_adaptive_constellation_soft_cf_impl.cc:89-103 (sigma = sqrt(noise) or 0.001)

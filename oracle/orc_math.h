@@ -1,0 +1,93 @@
+/*
+ * orc_math.h -- ORACLE (test infrastructure): float expf / logf / sincosf with a FIXED, documented
+ * operation sequence (IEEE single ops only, no FMA contraction), <= 2 ulp from the true value.
+ *
+ * Why: the reference calls libm (expf/logf in constellation::calc_soft_dec, sincosf in gr_expj and
+ * the oscillator); libm results differ between platforms in the last bit, and the LDPC decoder of a
+ * non-converging codeword amplifies such differences into different hard decisions.  Fixing the
+ * algorithm makes the soft-bit path bit-reproducible: gr_dtl_amd/csrc/dtl_math.h implements the same
+ * sequences on the GPU.  Algorithms: Cody-Waite range reduction + Taylor/minimax polynomials with the
+ * classic fdlibm single-precision coefficients (public domain algorithm descriptions).
+ */
+#ifndef ORC_MATH_H
+#define ORC_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline float orc_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t orc_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* exp(x): k = rint(x*log2e); r = x - k*ln2 (hi/lo); degree-7 polynomial; two-step scaling by 2^k */
+static inline float orc_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283905f) return INFINITY;
+    if (x < -103.97208f) return 0.0f;
+    float kf = rintf(x * 1.44269504f);
+    int k = (int)kf;
+    float r = x - kf * 0.693145752f;
+    r = r - kf * 1.42860677e-06f;
+    float p = 1.9841270e-4f;
+    p = p * r + 1.3888889e-3f;
+    p = p * r + 8.3333338e-3f;
+    p = p * r + 4.1666668e-2f;
+    p = p * r + 1.6666667e-1f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    int k1 = k / 2, k2 = k - k1; /* |k1|,|k2| <= 75: both scale factors are normal numbers */
+    float s1 = orc_bits2f((uint32_t)(k1 + 127) << 23), s2 = orc_bits2f((uint32_t)(k2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+/* log(x), x >= 0: fdlibm e_logf kernel */
+static inline float orc_logf(float x)
+{
+    if (x != x) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x = x * 33554432.0f; e = -25; } /* subnormal: scale by 2^25 */
+    uint32_t ix = orc_f2bits(x);
+    e += (int)(ix >> 23) - 127;
+    ix = (ix & 0x007fffffu) | 0x3f800000u; /* m in [1,2) */
+    float m = orc_bits2f(ix);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float R = z * (0.66666662693f + z * (0.40000972152f + z * (0.28498786688f + z * 0.24279078841f)));
+    float hfsq = 0.5f * f * f;
+    float ef = (float)e;
+    return ef * 6.9313812256e-01f + (f - (hfsq - (s * (hfsq + R) + ef * 9.0580006145e-06f)));
+}
+
+/* sin and cos of x, any finite x: reduction to [-pi, pi) in double, quadrant split, fdlibm kernels */
+static inline void orc_sincosf(float x, float* sn, float* cs)
+{
+    if (!(x == x) || x == INFINITY || x == -INFINITY) { *sn = *cs = NAN; return; }
+    double xd = (double)x;
+    if (xd >= 3.14159265358979323846 || xd < -3.14159265358979323846) {
+        double kk = floor((xd + 3.14159265358979323846) * (1.0 / 6.28318530717958647692));
+        xd = xd - 6.28318530717958647692 * kk;
+    }
+    float xr = (float)xd;
+    float qf = rintf(xr * 0.636619772f); /* 2/pi */
+    int q = (int)qf;
+    float r = xr - qf * 1.57079601e+00f;  /* pi/2 hi */
+    r = r - qf * 3.13916473e-07f;         /* pi/2 lo */
+    float z = r * r;
+    float sp = r + r * z * (-1.6666667163e-01f + z * (8.3333337680e-03f + z * (-1.9841270114e-04f + z * 2.7557314297e-06f)));
+    float cp = 1.0f - 0.5f * z + z * z * (4.1666667908e-02f + z * (-1.3888889225e-03f + z * (2.4801587642e-05f + z * -2.7557314297e-07f)));
+    switch (q & 3) {
+    case 0: *sn = sp; *cs = cp; break;
+    case 1: *sn = cp; *cs = -sp; break;
+    case 2: *sn = -sp; *cs = -cp; break;
+    default: *sn = -cp; *cs = sp; break;
+    }
+}
+
+#endif

@@ -12,6 +12,7 @@
  * ofdm_carrier_allocator_cvc, ofdm_cyclic_prefixer.
  */
 #include "oracle.h"
+#include "orc_math.h"
 
 #include <complex.h>
 #include <math.h>
@@ -259,8 +260,9 @@ void orc_cfo_mix(const orc_cfg* cfg, const orc_c32* iq, long n, const float* ang
         phase = fmod(phase + M_PI, 2.0 * M_PI);
         if (phase < 0) phase += 2.0 * M_PI;
         phase -= M_PI;
-        float ph = (float)phase;
-        cf osc = cosf(ph) + sinf(ph) * I;
+        float ph = (float)phase, sn, cs;
+        orc_sincosf(ph, &sn, &cs); /* sincosf with a fixed operation sequence, orc_math.h */
+        cf osc = cs + sn * I;
         cf smp = (i >= dly) ? to_cf(iq[i - dly]) : 0;
         cf r = (crealf(smp) * crealf(osc) - cimagf(smp) * cimagf(osc)) +
                (crealf(smp) * cimagf(osc) + cimagf(smp) * crealf(osc)) * I;
@@ -295,7 +297,8 @@ int orc_chanest(const orc_cfg* cfg, const orc_c32* sync_syms, orc_c32* taps)
         cf tmp = 0;
         for (int k = 0; k < N; k++)
             if (corr_v[k] != 0) tmp += conjf(to_cf(y1[k + g])) * conjf(corr_v[k]) * to_cf(y2[k + g]);
-        if (cabsf(tmp) > Bg_max) { Bg_max = cabsf(tmp); carr_offset = g; }
+        float mag = sqrtf(crealf(tmp) * crealf(tmp) + cimagf(tmp) * cimagf(tmp));
+        if (mag > Bg_max) { Bg_max = mag; carr_offset = g; }
     }
     /* get_chan_taps */
     for (int i = 0; i < N; i++) taps[i] = (orc_c32){ 0, 0 };
@@ -326,8 +329,9 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
     }
     /* per-symbol phase derotation (:170-177) */
     for (int i = 0; i < n_sym; i++) {
-        float ph = (float)(-(2.0 * M_PI) * carrier_offset * cp / N * (i + 1));
-        cf pc = cosf(ph) + sinf(ph) * I;
+        float ph = (float)(-(2.0 * M_PI) * carrier_offset * cp / N * (i + 1)), sn, cs;
+        orc_sincosf(ph, &sn, &cs);
+        cf pc = cs + sn * I;
         for (int k = 0; k < N; k++) out[(long)i * N + k] *= pc;
     }
     /* masks: ofdm_equalizer_1d_pilots ctor (input_is_shifted = true) + equalizer.cc:196-214 */
@@ -367,7 +371,7 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
             if (is_pilot) {
                 cf pilot_eq = out[p] / H[k];
                 /* mpsk_snr_est_simple::update: Welford mean/variance of |x| (double) */
-                double x = cabsf(pilot_eq);
+                double x = sqrtf(crealf(pilot_eq) * crealf(pilot_eq) + cimagf(pilot_eq) * cimagf(pilot_eq)); /* |x|, IEEE ops */
                 double y1_prime = y1 + (x - y1) / counter;
                 y2 += (x - y1) * (x - y1_prime);
                 y1 = y1_prime;
@@ -401,8 +405,9 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
         snr_out->noise_lin = pow(10, noise_db / 10.0);
     }
     /* channel state out, rotated by the frame's accumulated phase (:189-193) */
-    float ph = (float)((2.0 * M_PI) * carrier_offset * cp / N * n_sym);
-    cf pc = cosf(ph) + sinf(ph) * I;
+    float ph = (float)((2.0 * M_PI) * carrier_offset * cp / N * n_sym), sn, cs;
+    orc_sincosf(ph, &sn, &cs);
+    cf pc = cs + sn * I;
     for (int k = 0; k < N; k++) taps_io[k] = from_cf(H[k] * pc);
     free(out); free(occupied); free(pilot_mask); free(pilot_sym); free(H);
 }

@@ -213,10 +213,13 @@ static void tb_decode(orc_tbdec* d, int tb_len, int* avg_it)
         int k_ = payload_len / (tb_len - i);
         if (payload_len % (tb_len - i)) ++k_;
         payload_len -= k_;
-        memcpy(&d->full[(long)i * n], &d->rcv[rcv_idx], ncheck * sizeof(float));
-        rcv_idx += ncheck;
-        memcpy(&d->full[(long)i * n + ncheck], &d->rcv[rcv_idx], k_ * sizeof(float));
-        rcv_idx += k_;
+        /* The reference copies from RCV_BUF past its size() when frames of the TB were lost
+         * (tb_decoder.cc:175-182): undefined behaviour.  Restated as "soft bits that were never
+         * received carry no information": value 0. */
+        for (int j = 0; j < ncheck; j++, rcv_idx++)
+            d->full[(long)i * n + j] = (rcv_idx < d->rcv_size) ? d->rcv[rcv_idx] : 0.0f;
+        for (int j = 0; j < k_; j++, rcv_idx++)
+            d->full[(long)i * n + ncheck + j] = (rcv_idx < d->rcv_size) ? d->rcv[rcv_idx] : 0.0f;
         int nit = 0;
         orc_ldpc_decode(d->code, &d->full[(long)i * n], d->max_it, d->bp_sigma, cw_out, &nit);
         memcpy(&d->data[d_idx], cw_out, k_); /* reference copies k bits; later codewords overwrite the tail */

@@ -79,7 +79,7 @@ def test_gather_descriptor_shortened(oracle, dtl, cuda):
         full[i, :cw.size] = llr
         len0 = int(rng.integers(1, cw.size + 1))
         gap = int(rng.integers(0, 50))
-        descs[i] = CwDesc(pos, pos + len0 + gap, out_off, len0, int(k_used[i]))
+        descs[i] = CwDesc(pos, pos + len0 + gap, out_off, len0, cw.size - len0, int(k_used[i]), 0)
         stream.append((pos, llr[:len0]))
         stream.append((pos + len0 + gap, llr[len0:]))
         pos += cw.size + gap + 3
