@@ -383,6 +383,36 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 // ofdm_adaptive_constellation_soft_cf (soft_cf_impl.cc:89-148) or the hard demapper of the
 // no-FEC tail.
 // ------------------------------------------------------------------------------------------
+// constellation::calc_soft_dec (exact MAP over all M points, accumulation in point order) followed by
+// the LSB-first reversal of soft_cf_impl.cc:146.  BPS is a compile-time constant so that the bit tests
+// of the accumulation vanish; the arithmetic per point (dist, -dist/npwr, exp, adds in point order) is
+// the reference's.
+template <int BPS>
+__device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, float npwr, int dist_mode,
+                                                  float* __restrict__ o)
+{
+    constexpr int M = 1 << BPS;
+    float p0[BPS], p1[BPS];
+    cf32 lp[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) lp[m] = pts[m];
+#pragma unroll
+    for (int j = 0; j < BPS; j++) { p0[j] = 0.0f; p1[j] = 0.0f; }
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const float dr = s.re - lp[m].re, di = s.im - lp[m].im;
+        const float dist = dist_mode ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
+        const float d = dm_exp(-dist / npwr); // fixed-sequence expf (dtl_math.h)
+#pragma unroll
+        for (int j = 0; j < BPS; j++) {
+            if ((m >> j) & 1) p1[j] += d;
+            else p0[j] += d;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BPS; j++) o[j] = dm_log(p1[j]) - dm_log(p0[j]);
+}
+
 struct Welford {
     double n, mean, m2;
 };
@@ -507,37 +537,37 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
 
     // ofdm_serializer_vcc (symbols_skipped = 1) + soft / hard demapper
     const int bps = fd.cnst == 4 ? 4 : fd.cnst; // 1,2,3,4
-    const int M = 1 << bps;
     const float npwr = float(sqrt(s_stat.noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
     uint8_t* hard_syms = reinterpret_cast<uint8_t*>(buf); // no-FEC: symbol values (<= N*8 bytes available)
-    int q_base = 0;
-    for (int i = 0; i < L && q_base < fd.n_syms; i++) {
-        const int set = (1 + i) % t.n_occ_sets;
-        const int nocc = t.occ_len[set];
-        for (int r = tid; r < nocc; r += blockDim.x) {
-            const int q = q_base + r;
-            if (q >= fd.n_syms) continue;
-            const cf32 s = frame[i * N + t.occ_idx[set * t.max_occ + r]];
-            if (soft_syms) soft_syms[size_t(blockIdx.x) * t.frame_capacity + q] = s;
-            if (t.has_fec) {
-                // constellation::calc_soft_dec then reversed to LSB-first
-                float p0[kMaxBps] = { 0, 0, 0, 0 }, p1[kMaxBps] = { 0, 0, 0, 0 };
-                for (int m = 0; m < M; m++) {
-                    const float dr = s.re - pts[m].re, di = s.im - pts[m].im;
-                    const float dist = t.llr_dist_mode ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
-                    const float d = dm_exp(-dist / npwr); // fixed-sequence expf (dtl_math.h)
-#pragma unroll
-                    for (int j = 0; j < kMaxBps; j++) {
-                        if (j < bps) { if ((m >> j) & 1) p1[j] += d; else p0[j] += d; }
-                    }
-                }
-                float* o = llr_out + size_t(llr_off[blockIdx.x]) + size_t(q) * bps;
-#pragma unroll
-                for (int j = 0; j < kMaxBps; j++)
-                    if (j < bps) o[j] = dm_log(p1[j]) - dm_log(p0[j]);
+    auto demap_one = [&](int q, int i, int r, int set) {
+        const cf32 s = frame[i * N + t.occ_idx[set * t.max_occ + r]];
+        if (soft_syms) soft_syms[size_t(blockIdx.x) * t.frame_capacity + q] = s;
+        if (t.has_fec) {
+            float* o = llr_out + size_t(llr_off[blockIdx.x]) + size_t(q) * bps;
+            switch (bps) {
+            case 1: soft_demap_symbol<1>(s, pts, npwr, t.llr_dist_mode, o); break;
+            case 2: soft_demap_symbol<2>(s, pts, npwr, t.llr_dist_mode, o); break;
+            case 3: soft_demap_symbol<3>(s, pts, npwr, t.llr_dist_mode, o); break;
+            default: soft_demap_symbol<4>(s, pts, npwr, t.llr_dist_mode, o); break;
             }
         }
-        q_base += nocc;
+    };
+    if (t.n_occ_sets == 1) {
+        // one carrier set: symbol q sits on carrier (q mod nocc) of OFDM symbol (q div nocc); all lanes busy
+        const int nocc = t.occ_len[0];
+        for (int q = tid; q < fd.n_syms; q += blockDim.x) {
+            const int i = q / nocc;
+            if (i < L) demap_one(q, i, q - i * nocc, 0);
+        }
+    } else {
+        int q_base = 0;
+        for (int i = 0; i < L && q_base < fd.n_syms; i++) {
+            const int set = (1 + i) % t.n_occ_sets;
+            const int nocc = t.occ_len[set];
+            for (int r = tid; r < nocc; r += blockDim.x)
+                if (q_base + r < fd.n_syms) demap_one(q_base + r, i, r, set);
+            q_base += nocc;
+        }
     }
     if (!t.has_fec) {
         // no-FEC tail: ofdm_adaptive_constellation_decoder_cb + ofdm_adaptive_frame_pack_bb; the soft
