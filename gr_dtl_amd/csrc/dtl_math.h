@@ -29,9 +29,9 @@ __device__ __forceinline__ float dm_exp(float x)
     p = p * r + 0.5f;
     p = p * r + 1.0f;
     p = p * r + 1.0f;
-    const int k1 = k / 2, k2 = k - k1;
-    const float s1 = __int_as_float((k1 + 127) << 23), s2 = __int_as_float((k2 + 127) << 23);
-    return (p * s1) * s2;
+    // p * 2^k with a single rounding (v_ldexp_f32); bit-identical to the CPU oracle's two-step
+    // (p * 2^(k/2)) * 2^(k - k/2), whose first product is exact (tools/math_check.hip: all 2^32 inputs)
+    return ldexpf(p, k);
 }
 
 __device__ __forceinline__ float dm_log(float x)

@@ -56,6 +56,7 @@ private:
     NpShared np_sh_{};
     const uint16_t* np_col_ptr_ = nullptr;
     const uint16_t* np_perm_ = nullptr;
+    unsigned int* np_queue_ = nullptr;  // ticket counter of the codeword queue (one decode() in flight per decoder)
     size_t np_lds_ = 0;
     bool np_ok_ = false;
 };

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const floa
 // single copy of the code's index tables; waves never synchronise with each other.
 // ------------------------------------------------------------------------------------------
 constexpr int kNpWaves = 16;
+constexpr int kNpChunk = 16;  // codewords per queue ticket
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                                                                      const CwDesc* __restrict__ desc, int ncw,
                                                                      int max_it, float sigma,
                                                                      uint8_t* __restrict__ out_bits,
-                                                                     int32_t* __restrict__ out_nit)
+                                                                     int32_t* __restrict__ out_nit,
+                                                                     unsigned int* __restrict__ queue)
 {
     extern __shared__ unsigned char np_smem[];
     uint16_t* row_ptr = reinterpret_cast<uint16_t*>(np_smem + sh.row_ptr);
@@ -232,13 +234,31 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             vals[p] = val;
         }
     };
-    const int stride = gridDim.x * kNpWaves;
+    // Codewords are claimed kNpChunk at a time from a global ticket counter: the iteration count
+    // varies from 0 to max_it per codeword, so a static split would leave the slowest wave with up
+    // to 30 % more work than the average.  (One ticket per codeword would serialise millions of
+    // same-address device-scope atomics: measured 2.3x slower.)  The next codeword is known before
+    // the current one is decoded so that its soft bits can be prefetched.
+    const int n_chunks = (ncw + kNpChunk - 1) / kNpChunk;
+    int chunk_next = 0, chunk_end = 0;
+    auto advance = [&]() -> int {
+        if (chunk_next == chunk_end) {
+            unsigned v = 0;
+            if (lane == 0) v = atomicAdd(queue, 1u);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v >= unsigned(n_chunks)) return ncw;
+            chunk_next = int(v) * kNpChunk;
+            chunk_end = min(chunk_next + kNpChunk, ncw);
+        }
+        return chunk_next++;
+    };
     float cur[NV], nxt[NV];
     Meta mcur{ 0, 0 }, mnxt{ 0, 0 };
-    int cw = blockIdx.x * kNpWaves + wave;
+    int cw = advance();
     if (cw < ncw) fetch(cw, cur, mcur);
-    for (; cw < ncw; cw += stride) {
-        if (cw + stride < ncw) fetch(cw + stride, nxt, mnxt);
+    while (cw < ncw) {
+        const int cw_next = advance();
+        if (cw_next < ncw) fetch(cw_next, nxt, mnxt);
         const uint32_t out_off = mcur.out_off;
         const int k_used = mcur.k_used;
         // scatter to y[permute[i]] = -llr[i] (ldpc_dec.cc:64-66)
@@ -309,6 +329,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
 #pragma unroll
         for (int p = 0; p < NV; p++) cur[p] = nxt[p];
         mcur = mnxt;
+        cw = cw_next;
     }
 }
 
@@ -351,6 +372,8 @@ int LdpcDecoder::upload()
     std::vector<uint16_t> col_ptr16 = to16(code.col_ptr), perm16 = to16(code.permute);
     size_t o_cp = put(col_ptr16.data(), col_ptr16.size() * 2);
     size_t o_pm = put(perm16.data(), perm16.size() * 2);
+    const unsigned int zero = 0;
+    size_t o_q = put(&zero, sizeof(zero));
     if (blob_) { (void)hipFree(blob_); blob_ = nullptr; }
     DTL_HIP_CHECK(hipMalloc(&blob_, host.size()));
     DTL_HIP_CHECK(hipMemcpy(blob_, host.data(), host.size(), hipMemcpyHostToDevice));
@@ -366,6 +389,7 @@ int LdpcDecoder::upload()
     t_.sys_src = reinterpret_cast<const uint16_t*>(b + o_ss);
     np_col_ptr_ = reinterpret_cast<const uint16_t*>(b + o_cp);
     np_perm_ = reinterpret_cast<const uint16_t*>(b + o_pm);
+    np_queue_ = reinterpret_cast<unsigned int*>(b + o_q);
     // LDS plan of the node-parallel kernel: shared index tables + 16 per-wave slices
     {
         auto al = [](size_t v) { return (v + 15) & ~size_t(15); };
@@ -403,8 +427,10 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
         const int grid = int(std::min<size_t>((ncw + kNpWaves - 1) / kNpWaves, 256));
         auto kern = (code.max_row_deg <= 6 && code.max_col_deg <= 3 && code.n <= 320) ? ldpc_bp_np_kernel<6, 3, 5>
                                                                                          : ldpc_bp_np_kernel<8, 4, 8>;
+        // every wave stops at its first out-of-range ticket: the counter ends below n_chunks + #waves
+        DTL_HIP_CHECK(hipMemsetAsync(np_queue_, 0, sizeof(unsigned int), stream));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_col_ptr_, np_perm_,
-                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit);
+                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, np_queue_);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
     }
