@@ -386,10 +386,14 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 // constellation::calc_soft_dec (exact MAP over all M points, accumulation in point order) followed by
 // the LSB-first reversal of soft_cf_impl.cc:146.  BPS is a compile-time constant so that the bit tests
 // of the accumulation vanish; the arithmetic per point (dist, -dist/npwr, exp, adds in point order) is
-// the reference's.
+// the reference's.  The single-precision quotient -dist/npwr is formed as float(double(dist) * (-1/npwr)):
+// the f64 product is within 2^-52 of the exact quotient while a quotient of two floats is never closer
+// than 2^-49 (relative) to a rounding boundary of the float format, so the result IS the correctly
+// rounded IEEE quotient (3 full-rate instructions instead of the ~11 of v_div_scale/rcp/fma/fixup);
+// quotients in the subnormal range all map to exp() == 1.  tools/math_check.hip checks both claims.
 template <int BPS>
-__device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, float npwr, int dist_mode,
-                                                  float* __restrict__ o)
+__device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, double neg_inv_npwr,
+                                                  int dist_mode, float* __restrict__ o)
 {
     constexpr int M = 1 << BPS;
     float p0[BPS], p1[BPS];
@@ -402,7 +406,7 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
     for (int m = 0; m < M; m++) {
         const float dr = s.re - lp[m].re, di = s.im - lp[m].im;
         const float dist = dist_mode ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
-        const float d = dm_exp(-dist / npwr); // fixed-sequence expf (dtl_math.h)
+        const float d = dm_exp(float(double(dist) * neg_inv_npwr)); // fixed-sequence expf (dtl_math.h)
 #pragma unroll
         for (int j = 0; j < BPS; j++) {
             if ((m >> j) & 1) p1[j] += d;
@@ -459,9 +463,8 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
             const int dst = p - off;
             if (dst >= 0 && dst < total) {
                 const cf32 v = buf[u * N + ((tid + N / 2) & (N - 1))];
-                cf32 pc = { 1.0f, 0.0f };
+                cf32 pc = { 1.0f, -0.0f }; // expj(-0.0f): the value the formula below takes for off == 0
                 if (off != 0) pc = expj(float(-(2.0 * kPi) * off * t.cp_len / N * (dst / N + 1)));
-                else pc = expj(-0.0f);
                 frame[dst] = cmul(v, pc);
             }
         }
@@ -538,6 +541,7 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
     // ofdm_serializer_vcc (symbols_skipped = 1) + soft / hard demapper
     const int bps = fd.cnst == 4 ? 4 : fd.cnst; // 1,2,3,4
     const float npwr = float(sqrt(s_stat.noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
+    const double neg_inv_npwr = -1.0 / double(npwr);
     uint8_t* hard_syms = reinterpret_cast<uint8_t*>(buf); // no-FEC: symbol values (<= N*8 bytes available)
     auto demap_one = [&](int q, int i, int r, int set) {
         const cf32 s = frame[i * N + t.occ_idx[set * t.max_occ + r]];
@@ -545,10 +549,10 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
         if (t.has_fec) {
             float* o = llr_out + size_t(llr_off[blockIdx.x]) + size_t(q) * bps;
             switch (bps) {
-            case 1: soft_demap_symbol<1>(s, pts, npwr, t.llr_dist_mode, o); break;
-            case 2: soft_demap_symbol<2>(s, pts, npwr, t.llr_dist_mode, o); break;
-            case 3: soft_demap_symbol<3>(s, pts, npwr, t.llr_dist_mode, o); break;
-            default: soft_demap_symbol<4>(s, pts, npwr, t.llr_dist_mode, o); break;
+            case 1: soft_demap_symbol<1>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
+            case 2: soft_demap_symbol<2>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
+            case 3: soft_demap_symbol<3>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
+            default: soft_demap_symbol<4>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
             }
         }
     };

@@ -639,6 +639,8 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     std::vector<FrameDesc> fdesc;
     std::vector<uint32_t> llr_off;
     int state_cnst = 4; // d_constellation(QAM16), packet_header.cc:70
+    fdesc.reserve(n_cand);
+    frames.reserve(n_cand);
     {
         int64_t pos = 0;
         for (int ci = 0; ci < n_cand; ci++) {

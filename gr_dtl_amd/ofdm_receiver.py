@@ -60,7 +60,6 @@ class _Result(C.Structure):
                 ("pad", C.c_int32)]
 
 
-assert None is None
 WANT = {"eq_hard": 1, "eq_soft": 2, "soft_syms": 4, "hdr_bits": 8, "metric": 16}
 _FRAME_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4", C.c_double: "<f8"}[t]) for n, t in FrameInfo._fields_], align=True)
 _TB_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4"}[t]) for n, t in TbInfo._fields_], align=True)
@@ -222,14 +221,18 @@ class ofdm_receiver:
         out.n_codewords = int(res.n_codewords)
         out.stage_ms = list(res.stage_ms)
         nf, nt = int(res.n_frames), int(res.n_tbs)
-        out.frames = (np.ctypeslib.as_array(C.cast(res.frames, C.POINTER(C.c_uint8)), (nf * C.sizeof(FrameInfo),))
-                      .view(_FRAME_DTYPE).copy() if nf else np.zeros(0, _FRAME_DTYPE))
-        out.tbs = (np.ctypeslib.as_array(C.cast(res.tbs, C.POINTER(C.c_uint8)), (nt * C.sizeof(TbInfo),))
-                   .view(_TB_DTYPE).copy() if nt else np.zeros(0, _TB_DTYPE))
+        def records(ptr, count, dtype):
+            # one memmove (a structured-dtype .copy() goes field by field and costs milliseconds)
+            arr = np.empty(count, dtype=dtype)
+            if count:
+                C.memmove(arr.ctypes.data, ptr, count * arr.itemsize)
+            return arr
+        out.frames = records(res.frames, nf, _FRAME_DTYPE)
+        out.tbs = records(res.tbs, nt, _TB_DTYPE)
         nr, nx = int(res.n_raw_triggers), int(res.n_fixed_triggers)
-        out.raw_triggers = np.ctypeslib.as_array(res.raw_triggers, (nr,)).copy() if nr else np.zeros(0, np.int64)
-        out.fixed_triggers = np.ctypeslib.as_array(res.fixed_triggers, (nx,)).copy() if nx else np.zeros(0, np.int64)
-        out.sc_freq = np.ctypeslib.as_array(res.trigger_angles, (nr,)).copy() if nr else np.zeros(0, np.float32)
+        out.raw_triggers = records(res.raw_triggers, nr, np.int64)
+        out.fixed_triggers = records(res.fixed_triggers, nx, np.int64)
+        out.sc_freq = records(res.trigger_angles, nr, np.float32)
         out.n_payload_bytes = int(res.n_payload_bytes)
         if not copy_outputs:
             return out

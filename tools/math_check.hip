@@ -42,6 +42,36 @@ __global__ void check(unsigned long long* mism, unsigned* example)
     if (bad) atomicAdd(mism, bad);
 }
 
+// float(double(a) * (-1.0 / double(b))) == -a / b (IEEE single) for the demapper's operands
+__global__ void check_div(unsigned long long* mism, unsigned long long* total, unsigned* example)
+{
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 0xD1B54A32D192ED03ull;
+    auto rng = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    unsigned long long bad = 0, cnt = 0;
+    for (int ib = 0; ib < 64; ib++) {
+        // divisor: any positive normal float with exponent in [-40, 40] (sigma = sqrt(noise power))
+        const unsigned eb = 127 - 40 + unsigned(rng() % 81);
+        unsigned mb = unsigned(rng()) & 0x7fffffu;
+        if ((ib & 7) == 7) mb = 0x7fffffu - (unsigned(rng()) & 0xff); // all-ones significands (Markstein's hard case)
+        const float b = __int_as_float(int((eb << 23) | mb));
+        const double ninv = -1.0 / double(b);
+        for (int ia = 0; ia < 1024; ia++) {
+            const unsigned ea = 127 - 60 + unsigned(rng() % 81);
+            unsigned ma = unsigned(rng()) & 0x7fffffu;
+            if ((ia & 15) == 15) ma = unsigned(rng()) & 0xffu;
+            const float a = __int_as_float(int((ea << 23) | ma));
+            const float q0 = -a / b, q1 = float(double(a) * ninv);
+            cnt++;
+            const bool tiny = fabsf(q0) < 1.17549435e-38f;
+            // subnormal quotients may differ (double rounding) but exp() of both is exactly 1
+            const bool same = tiny ? (dtl::dm_exp(q0) == dtl::dm_exp(q1)) : (__float_as_int(q0) == __float_as_int(q1));
+            if (!same) { bad++; example[0] = unsigned(__float_as_int(a)); example[1] = unsigned(__float_as_int(b)); }
+        }
+    }
+    atomicAdd(mism, bad);
+    atomicAdd(total, cnt);
+}
+
 int main()
 {
     unsigned long long *d, h = 0;
@@ -52,5 +82,14 @@ int main()
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&hex_, ex, 4, hipMemcpyDeviceToHost);
     printf("dm_exp ldexp tail vs two-step scaling: %llu mismatches over 2^32 inputs (last example bits 0x%08x)\n", h, hex_);
-    return h != 0;
+    unsigned long long *d2, h2[2] = { 0, 0 };
+    unsigned *ex2, hex2[2] = { 0, 0 };
+    (void)hipMalloc(&d2, 16); (void)hipMalloc(&ex2, 8);
+    (void)hipMemset(d2, 0, 16); (void)hipMemset(ex2, 0, 8);
+    hipLaunchKernelGGL(check_div, dim3(8192), dim3(256), 0, 0, d2, d2 + 1, ex2);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h2, d2, 16, hipMemcpyDeviceToHost); (void)hipMemcpy(hex2, ex2, 8, hipMemcpyDeviceToHost);
+    printf("float(double(a) * (-1/b)) vs -a/b: %llu mismatches over %llu operand pairs (example a=0x%08x b=0x%08x)\n",
+           h2[0], h2[1], hex2[0], hex2[1]);
+    return (h != 0) || (h2[0] != 0);
 }
