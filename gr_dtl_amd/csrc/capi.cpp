@@ -169,12 +169,14 @@ int dtl_rx_create(const dtl_rx_cfg* c, dtl_rx** out)
 
 void dtl_rx_destroy(dtl_rx* h) { delete h; }
 
-int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void* stream, dtl_rx_result* out)
+static int rx_run(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, int mode, void* stream, dtl_rx_result* out)
 {
     if (!h || !out) { dtl::set_last_error("rx_process: null argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
     dtl::Receiver& r = h->rx;
-    int rc = r.process(reinterpret_cast<const dtl::cf32*>(d_iq), n, flags, static_cast<hipStream_t>(stream));
+    const auto* iq = reinterpret_cast<const dtl::cf32*>(d_iq);
+    auto* st = static_cast<hipStream_t>(stream);
+    int rc = mode < 0 ? r.process(iq, n, flags, st) : r.process_stream(iq, n, flags, mode != 0, st);
     if (rc != DTL_OK) return rc;
     std::memset(out, 0, sizeof(*out));
     out->n_frames = int64_t(r.frames.size());
@@ -205,6 +207,21 @@ int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void
     out->frame_samples = r.frame_samples();
     return DTL_OK;
 }
+
+int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void* stream, dtl_rx_result* out)
+{
+    return rx_run(h, d_iq, n, flags, -1, stream, out);
+}
+
+int dtl_rx_process_stream(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, int32_t final, void* stream,
+                          dtl_rx_result* out)
+{
+    return rx_run(h, d_iq, n, flags, final ? 1 : 0, stream, out);
+}
+
+void dtl_rx_reset(dtl_rx* h) { if (h) h->rx.reset_stream(); }
+
+int64_t dtl_rx_stream_position(const dtl_rx* h) { return h ? h->rx.stream_position() : 0; }
 
 int dtl_copy_device(void* dst, const void* src, size_t bytes, void* stream)
 {

@@ -7,8 +7,11 @@
 
 namespace dtl {
 
-int launch_sync_edges(const cf32* iq, int64_t n, int fft_len, float threshold, unsigned long long* edges,
-                      unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st);
+// edges / metric are produced for samples m_begin .. n-1 only (earlier samples are history of a stream
+// continued from a previous call); metric_out[m - m_begin]
+int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int fft_len, float threshold,
+                      unsigned long long* edges, unsigned int* n_edges, unsigned int max_edges, float* metric_out,
+                      hipStream_t st);
 int launch_trigger_angle(const cf32* iq, int64_t n, int fft_len, const int64_t* trig, int n_trig,
                          float* angle, hipStream_t st);
 int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate* cands, int n_cand,

@@ -159,7 +159,7 @@ constexpr int kSyncThreads = 256;
 constexpr int kSyncTile = 1024;
 
 __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
-                                                                 int N, float thr,
+                                                                 int64_t m_begin, int N, float thr,
                                                                  unsigned long long* __restrict__ edges,
                                                                  unsigned int* __restrict__ n_edges,
                                                                  unsigned int max_edges,
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
     extern __shared__ double sync_smem[];
     const int half = N / 2;
     const int M = kSyncTile + N + 1;               // prefix arrays cover samples j0 .. j0+M-1
-    const int64_t t0 = int64_t(blockIdx.x) * kSyncTile;
+    const int64_t t0 = (m_begin / kSyncTile + int64_t(blockIdx.x)) * kSyncTile; // tiles stay aligned to sample 0
     const int64_t j0 = t0 - N - 1;
     double* Sr = sync_smem;                        // prefix of c.re
     double* Si = Sr + M;                           // prefix of c.im
@@ -223,9 +223,11 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
         const int64_t m = m_first + s;
         if (m >= n) break;
         const float mt = metric_at(q_first + s);
-        if (metric_out) metric_out[m] = mt;
         const bool cur = mt >= thr;
-        if (cur != prev) {
+        if (m >= m_begin) {
+            if (metric_out) metric_out[m - m_begin] = mt;
+        }
+        if (cur != prev && m >= m_begin) {
             const unsigned int slot = atomicAdd(n_edges, 1u);
             if (slot < max_edges) edges[slot] = (static_cast<unsigned long long>(m) << 1) | (cur ? 1ull : 0ull);
         }
@@ -777,11 +779,12 @@ __global__ void nofec_lengths_kernel(const int32_t* __restrict__ info, int n, in
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-int launch_sync_edges(const cf32* iq, int64_t n, int N, float thr, unsigned long long* edges,
+int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int N, float thr, unsigned long long* edges,
                       unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st)
 {
+    if (m_begin < 0 || m_begin > n) return DTL_ERR_INVALID_ARG;
     const size_t lds = size_t(kSyncTile + N + 1) * 3 * sizeof(double) + size_t(kSyncTile + N + 1 + N / 2) * sizeof(cf32);
-    const int64_t grid = (n + kSyncTile - 1) / kSyncTile;
+    const int64_t grid = (n + kSyncTile - 1) / kSyncTile - m_begin / kSyncTile;
     if (grid <= 0) return DTL_OK;
     static size_t attr_lds = 64 * 1024;
     if (lds > attr_lds) {
@@ -789,8 +792,8 @@ int launch_sync_edges(const cf32* iq, int64_t n, int N, float thr, unsigned long
                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(sync_edges_kernel, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, N, thr, edges,
-                       n_edges, max_edges, metric_out);
+    hipLaunchKernelGGL(sync_edges_kernel, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, m_begin, N, thr,
+                       edges, n_edges, max_edges, metric_out);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

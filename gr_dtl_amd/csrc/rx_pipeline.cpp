@@ -335,6 +335,35 @@ struct TbAssembler {
 
 } // namespace
 
+// ------------------------------------------------------------------ stream state
+
+// Everything a continued stream needs from the calls before it.  Positions are absolute sample
+// indices (0 = first sample after reset_stream()).
+struct Receiver::StreamState {
+    int64_t next_abs = 0;                        // absolute index of the next new sample
+    int64_t carry_abs = 0, carry_len = 0;        // d_carry_ holds samples [carry_abs, carry_abs + carry_len)
+    std::vector<unsigned long long> edge_carry;  // rising edge of a plateau that is still open
+    int64_t plateau_i = 0;                       // plateau detector scan position
+    int64_t trig_produced = 0;                   // frame_detect_bb has seen the trigger stream up to here
+    std::vector<CfoSegment> segs;                // oscillator segments still needed (absolute starts)
+    FrameDetectState fds;
+    std::vector<int64_t> pending_fixed;          // triggers whose frame is not complete yet
+    int64_t demux_pos = 0;                       // header_payload_demux: samples consumed
+    int state_cnst = 4;                          // header parser: d_constellation(QAM16), packet_header.cc:70
+    TbAssembler asmb;                            // transport block being received
+    int64_t llr_carry_len = 0;                   // its soft bits, compacted in d_llr_carry_
+    FeedbackDecision fb;
+    bool fb_init = false;
+    int expected_frame_no = 0;
+    long lost_total = 0;
+};
+
+Receiver::Receiver() : ss_(std::make_unique<StreamState>()) {}
+
+void Receiver::reset_stream() { ss_ = std::make_unique<StreamState>(); }
+
+int64_t Receiver::stream_position() const { return ss_->next_abs; }
+
 // ------------------------------------------------------------------ Receiver
 
 Receiver::~Receiver()
@@ -504,6 +533,61 @@ int Receiver::upload_tables()
     return DTL_OK;
 }
 
+// plateau_detector_fb over a continued stream: `edges` (absolute, sorted) extend the carried ones; a run
+// that is still above the threshold at `end_abs` is left for the next call unless `final`.
+// *produced = every later trigger is >= this position.
+static std::vector<int64_t> plateau_stream(std::vector<unsigned long long>& carry, const std::vector<unsigned long long>& edges,
+                                           int64_t& scan_i, int64_t end_abs, int max_len, bool final, int64_t* produced)
+{
+    std::vector<std::pair<int64_t, int64_t>> runs;
+    int64_t open = -1;
+    auto feed = [&](unsigned long long e) {
+        const int64_t pos = int64_t(e >> 1);
+        if (e & 1ull) { if (open < 0) open = pos; }
+        else if (open >= 0) { runs.emplace_back(open, pos); open = -1; }
+    };
+    for (unsigned long long e : carry) feed(e);
+    for (unsigned long long e : edges) feed(e);
+    carry.clear();
+    *produced = end_abs;
+    if (open >= 0) {
+        if (final) runs.emplace_back(open, end_abs);
+        else { carry.push_back((static_cast<unsigned long long>(open) << 1) | 1ull); *produced = open; }
+    }
+    std::vector<int64_t> trig;
+    int64_t i = scan_i;
+    for (const auto& r : runs) {
+        if (r.second <= i) continue; // run entirely behind the scan position
+        const int64_t flank_start = std::max(i, r.first);
+        i = r.second; // first sample below threshold
+        if (i - flank_start > 1) { // "1 sample is not a plateau"
+            trig.push_back(flank_start + (i - flank_start) / 2);
+            i += max_len;
+        }
+        i++;
+    }
+    scan_i = i;
+    return trig;
+}
+
+static void sort_edges(std::vector<unsigned long long>& edges)
+{
+    // the kernel appends edges with an atomic counter: sort them (LSD radix, 3 x 11 bits cover 2^33)
+    if (edges.size() > 64) {
+        std::vector<unsigned long long> tmp(edges.size());
+        for (int pass = 0; pass < 3; pass++) {
+            size_t cnt[2049] = { 0 };
+            const int sh = pass * 11;
+            for (unsigned long long e : edges) cnt[((e >> sh) & 2047) + 1]++;
+            for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+            for (unsigned long long e : edges) tmp[cnt[(e >> sh) & 2047]++] = e;
+            edges.swap(tmp);
+        }
+    } else {
+        std::sort(edges.begin(), edges.end());
+    }
+}
+
 #define DTL_TRY(expr)                  \
     do {                               \
         int _rc = (expr);              \
@@ -512,13 +596,24 @@ int Receiver::upload_tables()
 
 int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t st)
 {
+    reset_stream();
+    return process_stream(d_iq, n, flags, true, st);
+}
+
+int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st)
+{
+    StreamState& ss = *ss_;
+    struct ResetOnExit { // a failed or final call ends the stream
+        Receiver* r; bool armed;
+        ~ResetOnExit() { if (armed) r->reset_stream(); }
+    } reset_guard{ this, true };
     if (n < 0 || (!d_iq && n > 0)) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
-    if (n == 0) { // an empty work() call: nothing consumed, nothing produced
-        frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
-        n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
-        return DTL_OK;
-    }
-    if (n > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
+    frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
+    n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
+    for (double& s : stage_ms) s = 0.0;
+    const int64_t W = ss.carry_len + n; // samples this call works on: carried tail + new ones
+    if (W == 0 || (n == 0 && !final)) { reset_guard.armed = final; return DTL_OK; } // nothing consumed, nothing produced
+    if (W > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
     if (!uploaded_) DTL_TRY(upload_tables());
     if (!ev_[0]) for (auto& e : ev_) DTL_HIP_CHECK(hipEventCreate(&e));
     const int N = cfg.fft_len, cp = cfg.cp_len, P = N + cp, h = cfg.header_len(), L = cfg.frame_length;
@@ -526,41 +621,54 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     const bool dbg = getenv("DTL_DEBUG") != nullptr;
     double tdbg = now_ms();
     auto lap = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "  [%s %.3f ms]\n", what, t - tdbg); tdbg = t; } };
-    frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
-    n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
     double t0 = now_ms();
-    lap("clear");
+
+    // ---- working buffer: [carried tail | new samples]; A = absolute index of its first sample (a
+    // multiple of the sync kernel's tile, so that every metric value is computed exactly as in one batch)
+    const int64_t A = ss.carry_len ? ss.carry_abs : ss.next_abs;
+    const int64_t B = ss.next_abs, E = B + n; // new samples are [B, E)
+    const cf32* iq = d_iq;
+    if (ss.carry_len) {
+        DTL_TRY(d_work_.ensure(size_t(W) * sizeof(cf32)));
+        DTL_HIP_CHECK(hipMemcpyAsync(d_work_.p, d_carry_.p, size_t(ss.carry_len) * sizeof(cf32), hipMemcpyDeviceToDevice, st));
+        if (n) DTL_HIP_CHECK(hipMemcpyAsync(d_work_.as<cf32>() + ss.carry_len, d_iq, size_t(n) * sizeof(cf32), hipMemcpyDeviceToDevice, st));
+        iq = d_work_.as<cf32>();
+    }
+    lap("work buffer");
 
     // ---- K1: timing metric -> threshold crossings -> plateau detector (host)
-    const unsigned max_edges = unsigned(std::min<int64_t>(std::max<int64_t>(n / 8, 1024), 1 << 26));
-    DTL_TRY(d_edges_.ensure(size_t(max_edges) * 8));
-    DTL_TRY(d_counter_.ensure(16));
-    lap("ensure");
-    DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 16, st));
-    lap("memset");
-    float* metric = nullptr;
-    if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
-    DTL_TRY(launch_sync_edges(d_iq, n, N, cfg.sync_threshold, d_edges_.as<unsigned long long>(),
-                              d_counter_.as<unsigned int>(), max_edges, metric, st));
-    lap("launch sync");
-    DTL_TRY(h_small_.ensure(64));
-    DTL_HIP_CHECK(hipMemcpyAsync(h_small_.p, d_counter_.p, 4, hipMemcpyDeviceToHost, st));
-    lap("memcpyasync");
-    DTL_HIP_CHECK(hipStreamSynchronize(st));
-    lap("sync wait");
-    const unsigned n_edges = *h_small_.as<unsigned>();
-    if (n_edges > max_edges) { set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
-    std::vector<unsigned long long> edges(n_edges);
-    if (n_edges) {
-        DTL_TRY(h_edges_.ensure(size_t(n_edges) * 8));
-        DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.p, d_edges_.p, size_t(n_edges) * 8, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> edges;
+    if (n > 0) {
+        const unsigned max_edges = unsigned(std::min<int64_t>(std::max<int64_t>(n / 8, 1024), 1 << 26));
+        DTL_TRY(d_edges_.ensure(size_t(max_edges) * 8));
+        DTL_TRY(d_counter_.ensure(16));
+        DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 16, st));
+        float* metric = nullptr;
+        if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
+        DTL_TRY(launch_sync_edges(iq, W, B - A, N, cfg.sync_threshold, d_edges_.as<unsigned long long>(),
+                                  d_counter_.as<unsigned int>(), max_edges, metric, st));
+        lap("launch sync");
+        DTL_TRY(h_small_.ensure(64));
+        DTL_HIP_CHECK(hipMemcpyAsync(h_small_.p, d_counter_.p, 4, hipMemcpyDeviceToHost, st));
         DTL_HIP_CHECK(hipStreamSynchronize(st));
-        std::memcpy(edges.data(), h_edges_.p, size_t(n_edges) * 8);
+        lap("sync wait");
+        const unsigned n_edges = *h_small_.as<unsigned>();
+        if (n_edges > max_edges) { set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
+        edges.resize(n_edges);
+        if (n_edges) {
+            DTL_TRY(h_edges_.ensure(size_t(n_edges) * 8));
+            DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.p, d_edges_.p, size_t(n_edges) * 8, hipMemcpyDeviceToHost, st));
+            DTL_HIP_CHECK(hipStreamSynchronize(st));
+            std::memcpy(edges.data(), h_edges_.p, size_t(n_edges) * 8);
+        }
+        lap("edges d2h");
+        dbg_n_edges = n_edges;
     }
-    lap("edges d2h");
     const double t_e = now_ms();
-    raw_triggers = plateau_from_edges(std::move(edges), n, cp);
-    dbg_n_edges = n_edges;
+    sort_edges(edges);
+    if (A) for (auto& e : edges) e += static_cast<unsigned long long>(A) << 1; // buffer-relative -> absolute
+    int64_t produced = E;
+    raw_triggers = plateau_stream(ss.edge_carry, edges, ss.plateau_i, E, cp, final, &produced);
     stage_ms[0] = now_ms() - t0; t0 = now_ms();
     dbg_plateau_ms = t0 - t_e;
 
@@ -568,49 +676,72 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     const int n_raw = int(raw_triggers.size());
     trigger_angles.assign(n_raw, 0.0f);
     if (n_raw) {
+        std::vector<int64_t> rel(raw_triggers);
+        for (auto& t : rel) t -= A;
         DTL_TRY(d_angle_.ensure(size_t(n_raw) * 4));
         DTL_TRY(h_angle_.ensure(size_t(n_raw) * 4));
-        DTL_TRY(upload_vec(h_trig_, d_trig_, raw_triggers, st));
-        DTL_TRY(launch_trigger_angle(d_iq, n, N, d_trig_.as<int64_t>(), n_raw, d_angle_.as<float>(), st));
+        DTL_TRY(upload_vec(h_trig_, d_trig_, rel, st));
+        DTL_TRY(launch_trigger_angle(iq, W, N, d_trig_.as<int64_t>(), n_raw, d_angle_.as<float>(), st));
         DTL_HIP_CHECK(hipMemcpyAsync(h_angle_.p, d_angle_.p, size_t(n_raw) * 4, hipMemcpyDeviceToHost, st));
         DTL_HIP_CHECK(hipStreamSynchronize(st));
         std::memcpy(trigger_angles.data(), h_angle_.p, size_t(n_raw) * 4);
     }
-    std::vector<CfoSegment> segs(n_raw);
     {
+        // the phase a segment starts with is the previous segment's phase advanced to the new trigger
+        // (before the first trigger the held angle is 0 and the phase stays 0)
         const float sens = float(-2.0 / N);
-        double phase = 0.0; // oscillator phase before the first trigger: held angle 0 => phase stays 0
+        ss.segs.reserve(ss.segs.size() + n_raw);
         for (int j = 0; j < n_raw; j++) {
-            segs[j].start = raw_triggers[j];
-            segs[j].angle = trigger_angles[j];
-            segs[j].phase0 = phase;
-            segs[j].pad = 0;
-            const int64_t next = (j + 1 < n_raw) ? raw_triggers[j + 1] : n;
-            phase = phase + double(sens * trigger_angles[j]) * double(next - raw_triggers[j]);
-            phase = std::fmod(phase + M_PI, 2.0 * M_PI);
-            if (phase < 0) phase += 2.0 * M_PI;
-            phase -= M_PI;
+            CfoSegment sg{};
+            sg.start = raw_triggers[j];
+            sg.angle = trigger_angles[j];
+            sg.phase0 = 0.0;
+            if (!ss.segs.empty()) {
+                const CfoSegment& pv = ss.segs.back();
+                double phase = pv.phase0 + double(sens * pv.angle) * double(sg.start - pv.start);
+                phase = std::fmod(phase + M_PI, 2.0 * M_PI);
+                if (phase < 0) phase += 2.0 * M_PI;
+                phase -= M_PI;
+                sg.phase0 = phase;
+            }
+            ss.segs.push_back(sg);
         }
     }
-    // ---- frame_detect_bb (optional) -> candidates for phase A
+    const int n_segs = int(ss.segs.size());
+    // ---- frame_detect_bb (optional): one work() buffer = the trigger stream produced by this call
+    std::vector<int64_t> new_fixed;
     if (cfg.use_sync_correct) {
-        FrameDetectState fds;
-        fds.frame_len = (L + hdr_syms) * P; // ofdm_receiver.py:77-78
-        fixed_triggers = fix_sync_sparse(fds, raw_triggers, n);
+        ss.fds.frame_len = (L + hdr_syms) * P; // ofdm_receiver.py:77-78
+        const int64_t c0 = ss.trig_produced, len = produced - c0;
+        if (len > 0) {
+            std::vector<int64_t> rel(raw_triggers);
+            for (auto& t : rel) t -= c0;
+            new_fixed = fix_sync_sparse(ss.fds, rel, len);
+            for (auto& t : new_fixed) t += c0;
+        }
     } else {
-        fixed_triggers = raw_triggers;
+        new_fixed = raw_triggers;
     }
+    ss.trig_produced = produced;
+    fixed_triggers = new_fixed;
+    ss.pending_fixed.insert(ss.pending_fixed.end(), new_fixed.begin(), new_fixed.end());
+    // candidates for phase A: every pending trigger whose samples are here (a continued stream waits
+    // for the whole frame, the end of a stream only needs the header symbols)
     std::vector<Candidate> cands;
-    cands.reserve(fixed_triggers.size());
+    std::vector<int64_t> cand_abs;
+    cands.reserve(ss.pending_fixed.size());
+    cand_abs.reserve(ss.pending_fixed.size());
     {
-        size_t ri = 0; // number of raw triggers <= tpos (both lists are sorted)
-        for (int64_t tpos : fixed_triggers) {
-            if (tpos + int64_t(hdr_syms) * P > n) break;
-            while (ri < raw_triggers.size() && raw_triggers[ri] <= tpos) ri++;
+        size_t ri = 0; // number of segments starting <= tpos (both lists are sorted)
+        const int64_t need = int64_t(final ? hdr_syms : hdr_syms + L) * P;
+        for (int64_t tpos : ss.pending_fixed) {
+            if (tpos + need > E) break;
+            while (ri < ss.segs.size() && ss.segs[ri].start <= tpos) ri++;
             Candidate c{};
-            c.trigger = tpos;
+            c.trigger = tpos - A;
             c.seg = int(ri) - 1;
             cands.push_back(c);
+            cand_abs.push_back(tpos);
         }
     }
     const int n_cand = int(cands.size());
@@ -619,15 +750,17 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     // ---- phase A: header kernel
     std::vector<HeaderRec> recs(n_cand);
     if (n_cand) {
-        DTL_TRY(d_segs_.ensure(std::max<size_t>(1, segs.size()) * sizeof(CfoSegment)));
+        std::vector<CfoSegment> segs_rel(ss.segs);
+        for (auto& sg : segs_rel) sg.start -= A;
+        DTL_TRY(d_segs_.ensure(std::max<size_t>(1, segs_rel.size()) * sizeof(CfoSegment)));
         DTL_TRY(d_recs_.ensure(size_t(n_cand) * sizeof(HeaderRec)));
         DTL_TRY(h_recs_.ensure(size_t(n_cand) * sizeof(HeaderRec)));
         DTL_TRY(d_taps.ensure(size_t(n_cand) * N * sizeof(cf32)));
         uint8_t* hb = nullptr;
         if (flags & RX_WANT_HDR_BITS) { DTL_TRY(d_hdr_bits.ensure(size_t(n_cand) * tab_.hdr_bits)); hb = d_hdr_bits.as<uint8_t>(); }
         DTL_TRY(upload_vec(h_cands_, d_cands_, cands, st));
-        DTL_TRY(upload_vec(h_segs_, d_segs_, segs, st));
-        DTL_TRY(launch_header(tab_, d_iq, n, d_cands_.as<Candidate>(), n_cand, d_segs_.as<CfoSegment>(), n_raw,
+        DTL_TRY(upload_vec(h_segs_, d_segs_, segs_rel, st));
+        DTL_TRY(launch_header(tab_, iq, W, d_cands_.as<Candidate>(), n_cand, d_segs_.as<CfoSegment>(), n_segs,
                               d_recs_.as<HeaderRec>(), d_taps.as<cf32>(), hb, st));
         DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.p, d_recs_.p, size_t(n_cand) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
         DTL_HIP_CHECK(hipStreamSynchronize(st));
@@ -638,43 +771,43 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     // ---- header_payload_demux walk + header_parser state
     std::vector<FrameDesc> fdesc;
     std::vector<uint32_t> llr_off;
-    int state_cnst = 4; // d_constellation(QAM16), packet_header.cc:70
     fdesc.reserve(n_cand);
     frames.reserve(n_cand);
-    {
-        int64_t pos = 0;
-        for (int ci = 0; ci < n_cand; ci++) {
-            const int64_t trig = cands[ci].trigger;
-            if (trig < pos) continue; // consumed by a previous frame
-            const HeaderRec& r = recs[ci];
-            FrameInfo fi{};
-            fi.trigger = trig; fi.header_ok = r.crc_ok; fi.carr_offset = r.carr_offset; fi.payload_index = -1; fi.cand = ci;
-            fi.llr_offset = -1;
-            if (!r.crc_ok) { frames.push_back(fi); pos = trig + 1; continue; }
-            if (trig + int64_t(hdr_syms + L) * P > n) break;
-            if (r.cnst && r.cnst <= 4) state_cnst = r.cnst; // :269-273
-            const int bps = bits_per_symbol(state_cnst);
-            int n_syms = r.payload_len * 8 / bps;
-            if (r.payload_len * 8 % bps) n_syms++;
-            fi.payload_len = r.payload_len; fi.frame_no = r.frame_no; fi.cnst = state_cnst; fi.fb_cnst = r.fb_cnst;
-            fi.tb_no = r.tb_no; fi.fec_fb = r.fec_fb; fi.tb_offset = r.tb_offset; fi.fec = r.fec; fi.tb_payload = r.tb_payload;
-            fi.n_payload_syms = n_syms;
-            fi.payload_index = int(fdesc.size());
-            FrameDesc d{};
-            d.trigger = trig; d.seg = cands[ci].seg; d.cand = ci; d.cnst = state_cnst; d.carr_offset = r.carr_offset;
-            // ofdm_serializer_vcc truncation to packet_length; payload == 0 frames are dropped (:218,254)
-            d.n_syms = r.payload_len ? std::min(n_syms, capacity_) : 0;
-            fdesc.push_back(d);
-            frames.push_back(fi);
-            pos = trig + int64_t(hdr_syms + L) * P;
-        }
+    int n_walked = 0; // candidates the demux has dealt with
+    for (int ci = 0; ci < n_cand; ci++) {
+        const int64_t trig = cand_abs[ci];
+        n_walked = ci + 1;
+        if (trig < ss.demux_pos) continue; // consumed by a previous frame
+        const HeaderRec& r = recs[ci];
+        FrameInfo fi{};
+        fi.trigger = trig; fi.header_ok = r.crc_ok; fi.carr_offset = r.carr_offset; fi.payload_index = -1; fi.cand = ci;
+        fi.llr_offset = -1;
+        if (!r.crc_ok) { frames.push_back(fi); ss.demux_pos = trig + 1; continue; }
+        if (trig + int64_t(hdr_syms + L) * P > E) break; // only at the end of a stream
+        if (r.cnst && r.cnst <= 4) ss.state_cnst = r.cnst; // :269-273
+        const int bps = bits_per_symbol(ss.state_cnst);
+        int n_syms = r.payload_len * 8 / bps;
+        if (r.payload_len * 8 % bps) n_syms++;
+        fi.payload_len = r.payload_len; fi.frame_no = r.frame_no; fi.cnst = ss.state_cnst; fi.fb_cnst = r.fb_cnst;
+        fi.tb_no = r.tb_no; fi.fec_fb = r.fec_fb; fi.tb_offset = r.tb_offset; fi.fec = r.fec; fi.tb_payload = r.tb_payload;
+        fi.n_payload_syms = n_syms;
+        fi.payload_index = int(fdesc.size());
+        FrameDesc d{};
+        d.trigger = trig - A; d.seg = cands[ci].seg; d.cand = ci; d.cnst = ss.state_cnst; d.carr_offset = r.carr_offset;
+        // ofdm_serializer_vcc truncation to packet_length; payload == 0 frames are dropped (:218,254)
+        d.n_syms = r.payload_len ? std::min(n_syms, capacity_) : 0;
+        fdesc.push_back(d);
+        frames.push_back(fi);
+        ss.demux_pos = trig + int64_t(hdr_syms + L) * P;
     }
+    ss.pending_fixed.erase(ss.pending_fixed.begin(), ss.pending_fixed.begin() + n_walked);
     const int n_frames = int(fdesc.size());
     n_payload_frames = n_frames;
 
-    // ---- soft-bit stream layout + transport-block gather tables (tb_decoder::process_frame)
+    // ---- soft-bit stream layout (after the soft bits carried for an unfinished transport block)
+    // + transport-block gather tables (tb_decoder::process_frame)
     llr_off.assign(n_frames, 0);
-    uint64_t llr_total = 0;
+    uint64_t llr_total = uint64_t(ss.llr_carry_len);
     for (int f = 0; f < n_frames; f++) {
         llr_off[f] = uint32_t(llr_total);
         llr_total += uint64_t(fdesc[f].n_syms) * bits_per_symbol(fdesc[f].cnst);
@@ -691,16 +824,20 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     std::vector<int32_t> nofec_info(size_t(n_frames) * 2, 0);
     uint32_t total_bytes = 0;
     const int nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
+    if (n_frames || ss.llr_carry_len) {
+        DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
+        if (ss.llr_carry_len)
+            DTL_HIP_CHECK(hipMemcpyAsync(d_llr.p, d_llr_carry_.p, size_t(ss.llr_carry_len) * 4, hipMemcpyDeviceToDevice, st));
+    }
     if (n_frames) {
         DTL_TRY(d_stats_.ensure(size_t(n_frames) * sizeof(FrameStat)));
-        DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
-        cf32 *eh = nullptr, *es = nullptr, *ss = nullptr;
+        cf32 *eh = nullptr, *es = nullptr, *ss_out = nullptr;
         if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_frames) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
         if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_frames) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
         if (flags & RX_WANT_SOFT_SYMS) {
             DTL_TRY(d_soft_syms.ensure(size_t(n_frames) * capacity_ * sizeof(cf32)));
             DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_frames) * capacity_ * sizeof(cf32), st));
-            ss = d_soft_syms.as<cf32>();
+            ss_out = d_soft_syms.as<cf32>();
         }
         uint8_t* nofec_bytes = nullptr;
         int32_t* nofec_inf = nullptr;
@@ -714,12 +851,13 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
         DTL_TRY(upload_vec(h_frames_, d_frames_, fdesc, st));
         DTL_TRY(upload_vec(h_llr_off_, d_llr_off_, llr_off, st));
         if (ev_[0]) DTL_HIP_CHECK(hipEventRecord(ev_[0], st));
-        DTL_TRY(launch_payload(tab_, d_iq, n, d_frames_.as<FrameDesc>(), n_frames, d_segs_.as<CfoSegment>(), n_raw,
+        DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>(), n_frames, d_segs_.as<CfoSegment>(), n_segs,
                                d_taps.as<cf32>(), d_stats_.as<FrameStat>(), d_llr_off_.as<uint32_t>(),
-                               d_llr.as<float>(), eh, es, ss, nofec_bytes, nofec_inf, nofec_stride, st));
+                               d_llr.as<float>(), eh, es, ss_out, nofec_bytes, nofec_inf, nofec_stride, st));
         if (ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
     }
-    TbAssembler asmb;
+    TbAssembler& asmb = ss.asmb;
+    asmb.done.clear();
     if (cfg.has_fec) {
         int max_n = 0, max_bps = 0;
         for (auto& d : decoders_) if (d) max_n = std::max(max_n, d->code.n);
@@ -873,22 +1011,19 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
 
     // ---- per-frame sequential bookkeeping: lost frames (:124-138), feedback decision
     {
-        FeedbackDecision fb;
-        fb.init(cfg.mcs, cfg.hysteresis, cfg.decision_th, cfg.initial_mcs);
-        int expected_frame_no = 0;
-        long lost_total = 0;
+        if (!ss.fb_init) { ss.fb.init(cfg.mcs, cfg.hysteresis, cfg.decision_th, cfg.initial_mcs); ss.fb_init = true; }
         size_t fidx = 0;
         for (auto& fi : frames) {
             if (fi.payload_index < 0) continue;
             const FrameStat& s = stats[fidx++];
             int lost = 0;
-            if (fi.frame_no != expected_frame_no)
-                lost = fi.frame_no < expected_frame_no ? 4096 + fi.frame_no - expected_frame_no : fi.frame_no - expected_frame_no;
-            lost_total += lost;
-            expected_frame_no = (fi.frame_no + 1) % 4096;
+            if (fi.frame_no != ss.expected_frame_no)
+                lost = fi.frame_no < ss.expected_frame_no ? 4096 + fi.frame_no - ss.expected_frame_no : fi.frame_no - ss.expected_frame_no;
+            ss.lost_total += lost;
+            ss.expected_frame_no = (fi.frame_no + 1) % 4096;
             fi.snr_db = s.snr_db; fi.noise = s.noise_lin;
-            fb.get(s.snr_db, &fi.feedback_cnst, &fi.feedback_fec);
-            fi.lost_frames = int(lost_total);
+            ss.fb.get(s.snr_db, &fi.feedback_cnst, &fi.feedback_fec);
+            fi.lost_frames = int(ss.lost_total);
         }
     }
     // ---- TB records
@@ -919,6 +1054,59 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     }
     stage_ms[5] = now_ms() - t0;
     if (dbg) fprintf(stderr, "  [n_edges=%u plateau %.3f ms]\n", dbg_n_edges, dbg_plateau_ms);
+    if (final) return DTL_OK; // reset_guard ends the stream
+
+    // ---- what the next call needs from this one
+    // (a) soft bits of the transport block still being received, compacted into d_llr_carry_
+    if (cfg.has_fec && !asmb.rcv.empty()) {
+        size_t tot = 0;
+        for (const auto& sg : asmb.rcv) if (sg.off != 0xFFFFFFFFu) tot += size_t(sg.len);
+        DTL_TRY(d_llr_carry_.ensure(std::max<size_t>(tot, 1) * 4));
+        size_t at = 0;
+        std::vector<TbAssembler::Seg> merged; // pieces that end up adjacent in the carry become one segment
+        for (const auto& sg : asmb.rcv) {
+            if (sg.off == 0xFFFFFFFFu) { merged.push_back(sg); continue; }
+            DTL_HIP_CHECK(hipMemcpyAsync(d_llr_carry_.as<float>() + at, d_llr.as<float>() + sg.off, size_t(sg.len) * 4,
+                                         hipMemcpyDeviceToDevice, st));
+            if (!merged.empty() && merged.back().off != 0xFFFFFFFFu) merged.back().len += sg.len;
+            else merged.push_back({ uint32_t(at), sg.len });
+            at += size_t(sg.len);
+        }
+        asmb.rcv.swap(merged);
+        ss.llr_carry_len = int64_t(tot);
+    } else {
+        ss.llr_carry_len = 0;
+    }
+    // (b) samples: from the first trigger whose frame is still incomplete (the demux delays the stream
+    // by one symbol), and in any case the history the timing metric / arg(P) windows of the next
+    // samples reach back to; rounded down to the sync kernel's tile
+    {
+        auto& pf = ss.pending_fixed;
+        pf.erase(std::remove_if(pf.begin(), pf.end(), [&](int64_t t) { return t < ss.demux_pos; }), pf.end());
+        const int64_t hist = 2L * N + cp + 2;
+        int64_t keep = produced - hist;
+        if (!pf.empty()) keep = std::min(keep, pf.front() - P);
+        // a plateau that never ends (e.g. a constant input) must not grow the carry without bound
+        const int64_t max_carry = 4L * frame_samples() + hist;
+        if (E - keep > max_carry) {
+            keep = E - max_carry;
+            pf.erase(std::remove_if(pf.begin(), pf.end(), [&](int64_t t) { return t - P < keep; }), pf.end());
+        }
+        keep = std::max<int64_t>(std::max<int64_t>(keep, A), 0);
+        keep &= ~int64_t(1023);
+        const int64_t len = E - keep;
+        DTL_TRY(d_carry_.ensure(std::max<size_t>(size_t(len), 1) * sizeof(cf32)));
+        if (len) DTL_HIP_CHECK(hipMemcpyAsync(d_carry_.p, iq + (keep - A), size_t(len) * sizeof(cf32), hipMemcpyDeviceToDevice, st));
+        ss.carry_abs = keep;
+        ss.carry_len = len;
+        // oscillator segments: the one active at `keep - P` and everything after it
+        size_t first = 0;
+        while (first + 1 < ss.segs.size() && ss.segs[first + 1].start <= keep - P) first++;
+        if (first) ss.segs.erase(ss.segs.begin(), ss.segs.begin() + first);
+    }
+    DTL_HIP_CHECK(hipStreamSynchronize(st)); // the caller may reuse its buffer; d_work_ is reused by the next call
+    ss.next_abs = E;
+    reset_guard.armed = false;
     return DTL_OK;
 }
 

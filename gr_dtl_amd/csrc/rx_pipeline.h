@@ -103,9 +103,18 @@ struct HostBuf {
 class Receiver {
 public:
     RxConfig cfg;
+    Receiver();
     ~Receiver();
     int init(); // validate, derive tables, parse codes (no GPU needed)
+    // one self-contained batch: the stream starts at d_iq[0] and ends at d_iq[n-1]
     int process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t stream);
+    // streaming form: consecutive calls continue one sample stream (what a GNU Radio block's work()
+    // sees).  Detector / oscillator / demux / transport-block / feedback state and the samples of
+    // frames that are not complete yet are carried to the next call; `final` flushes the stream the
+    // way process() treats the end of its batch and resets the state.
+    int process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream);
+    void reset_stream();
+    int64_t stream_position() const; // samples consumed since the last reset
 
     // results of the last process() call
     std::vector<FrameInfo> frames;   // every trigger the demux visited, in order
@@ -126,6 +135,8 @@ public:
     const std::vector<std::unique_ptr<LdpcDecoder>>& decoders() const { return decoders_; }
 
 private:
+    struct StreamState;
+    std::unique_ptr<StreamState> ss_;
     int upload_tables();
     RxTables tab_{};
     DevBuf tab_blob_;
@@ -137,6 +148,7 @@ private:
         d_cwdesc_, d_tbgather_, d_tbdesc_, d_tbres_, d_len_, d_offs_, d_total_, d_staging_, d_nofec_info_;
     HostBuf h_small_, h_edges_, h_trig_, h_angle_, h_cands_, h_segs_, h_recs_, h_frames_, h_llr_off_, h_gather_,
         h_tbdesc_, h_stats_, h_tbres_, h_nofec_;
+    DevBuf d_work_, d_carry_, d_llr_carry_;
 };
 
 } // namespace dtl

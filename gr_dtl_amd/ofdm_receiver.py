@@ -186,6 +186,12 @@ class ofdm_receiver:
         L.dtl_rx_destroy.argtypes = [C.c_void_p]
         L.dtl_rx_destroy.restype = None
         L.dtl_rx_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.POINTER(_Result)]
+        L.dtl_rx_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int32, C.c_void_p,
+                                            C.POINTER(_Result)]
+        L.dtl_rx_reset.argtypes = [C.c_void_p]
+        L.dtl_rx_reset.restype = None
+        L.dtl_rx_stream_position.argtypes = [C.c_void_p]
+        L.dtl_rx_stream_position.restype = C.c_int64
         L.dtl_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L._rx_declared = True
 
@@ -202,8 +208,25 @@ class ofdm_receiver:
 
     # -- batched work() -----------------------------------------------------------------------
     def work(self, iq, want=(), copy_outputs=True):
-        """iq: complex64 CUDA tensor (1-D).  want: any of eq_hard, eq_soft, soft_syms, hdr_bits, metric,
-        llr, taps, cw.  Returns rx_result."""
+        """One self-contained batch.  iq: complex64 CUDA tensor (1-D).  want: any of eq_hard, eq_soft,
+        soft_syms, hdr_bits, metric, llr, taps, cw.  Returns rx_result."""
+        return self._run(iq, want, copy_outputs, None)
+
+    def feed(self, iq, want=(), final=False, copy_outputs=True):
+        """Streaming work(): continues the sample stream of the previous feed() calls (the way the GNU Radio
+        scheduler hands consecutive buffers to the reference hier block).  Detector, oscillator, demux,
+        transport-block and feedback state persist; samples of incomplete frames stay on the device.
+        Trigger positions are absolute.  final=True flushes and resets the stream."""
+        return self._run(iq, want, copy_outputs, bool(final))
+
+    def reset(self):
+        _lib.lib().dtl_rx_reset(self._h)
+
+    @property
+    def stream_position(self):
+        return int(_lib.lib().dtl_rx_stream_position(self._h))
+
+    def _run(self, iq, want, copy_outputs, final):
         import torch
         if not (hasattr(iq, "is_cuda") and iq.is_cuda):
             raise _lib.DtlError(_lib.ERR_NO_DEVICE, "ofdm_receiver.work needs a device tensor (no CPU fallback)")
@@ -215,7 +238,11 @@ class ofdm_receiver:
             flags |= WANT.get(w, 0)
         res = _Result()
         st = _lib.current_stream_ptr()
-        _lib.check(_lib.lib().dtl_rx_process(self._h, iq.data_ptr(), iq.numel(), flags, st, C.byref(res)))
+        if final is None:
+            _lib.check(_lib.lib().dtl_rx_process(self._h, iq.data_ptr(), iq.numel(), flags, st, C.byref(res)))
+        else:
+            _lib.check(_lib.lib().dtl_rx_process_stream(self._h, iq.data_ptr(), iq.numel(), flags, int(final), st,
+                                                        C.byref(res)))
         out = rx_result()
         out.n_payload_frames = int(res.n_payload_frames)
         out.n_codewords = int(res.n_codewords)

@@ -175,6 +175,23 @@ void dtl_rx_destroy(dtl_rx* h);
 /* d_iq: n_samples complex64 (re,im) on the device */
 int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t flags, void* stream,
                    dtl_rx_result* out);
+/* Streaming form -- what the reference hier block's work() calls amount to (python/dtl/ofdm_receiver.py:59-246
+ * run by the GNU Radio scheduler on consecutive buffers): each call continues the sample stream of the
+ * previous one.  The Schmidl-Cox/plateau detector, the fine-CFO oscillator, frame_detect_bb, the demux
+ * position, the header parser's "previous MCS", the transport block being received (tb_decoder.cc) and
+ * the feedback decision keep their state; samples of frames that are not complete yet are kept on the
+ * device and re-joined with the next call's samples.  Trigger positions in the result are absolute
+ * (samples since the last reset).  final != 0 ends the stream the way dtl_rx_process ends its batch
+ * (the detector closes an open plateau, incomplete frames are dropped) and resets the state;
+ * dtl_rx_process(h, x, n) == dtl_rx_reset(h) + dtl_rx_process_stream(h, x, n, final = 1).
+ * Any number of calls that cut the same stream at arbitrary points returns the same frames, transport
+ * blocks and payload bytes as one batch call, except that frame_detect_bb -- as in the reference --
+ * looks ahead only to the end of the buffer it is given (use_sync_correct = 0 removes that caveat). */
+int dtl_rx_process_stream(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t flags, int32_t final,
+                          void* stream, dtl_rx_result* out);
+void dtl_rx_reset(dtl_rx* h);
+/* samples consumed since the last reset */
+int64_t dtl_rx_stream_position(const dtl_rx* h);
 
 /* device-to-device copy on `stream` (lets a host binding snapshot result buffers it does not own) */
 int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);
