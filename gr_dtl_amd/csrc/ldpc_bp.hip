@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const floa
 // single copy of the code's index tables; waves never synchronise with each other.
 // ------------------------------------------------------------------------------------------
 constexpr int kNpWaves = 16;
-constexpr int kNpChunk = 16;  // codewords per queue ticket
+constexpr int kNpChunk = 16;  // codewords per queue ticket (large batches)
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                                                                      int max_it, float sigma,
                                                                      uint8_t* __restrict__ out_bits,
                                                                      int32_t* __restrict__ out_nit,
-                                                                     unsigned int* __restrict__ queue)
+                                                                     unsigned int* __restrict__ queue, int chunk)
 {
     extern __shared__ unsigned char np_smem[];
     uint16_t* row_ptr = reinterpret_cast<uint16_t*>(np_smem + sh.row_ptr);
@@ -234,12 +234,12 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             vals[p] = val;
         }
     };
-    // Codewords are claimed kNpChunk at a time from a global ticket counter: the iteration count
+    // Codewords are claimed `chunk` at a time from a global ticket counter: the iteration count
     // varies from 0 to max_it per codeword, so a static split would leave the slowest wave with up
     // to 30 % more work than the average.  (One ticket per codeword would serialise millions of
     // same-address device-scope atomics: measured 2.3x slower.)  The next codeword is known before
     // the current one is decoded so that its soft bits can be prefetched.
-    const int n_chunks = (ncw + kNpChunk - 1) / kNpChunk;
+    const int n_chunks = (ncw + chunk - 1) / chunk;
     int chunk_next = 0, chunk_end = 0;
     auto advance = [&]() -> int {
         if (chunk_next == chunk_end) {
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             if (lane == 0) v = atomicAdd(queue, 1u);
             v = __builtin_amdgcn_readfirstlane(v);
             if (v >= unsigned(n_chunks)) return ncw;
-            chunk_next = int(v) * kNpChunk;
-            chunk_end = min(chunk_next + kNpChunk, ncw);
+            chunk_next = int(v) * chunk;
+            chunk_end = min(chunk_next + chunk, ncw);
         }
         return chunk_next++;
     };
@@ -427,10 +427,13 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
         const int grid = int(std::min<size_t>((ncw + kNpWaves - 1) / kNpWaves, 256));
         auto kern = (code.max_row_deg <= 6 && code.max_col_deg <= 3 && code.n <= 320) ? ldpc_bp_np_kernel<6, 3, 5>
                                                                                          : ldpc_bp_np_kernel<8, 4, 8>;
-        // every wave stops at its first out-of-range ticket: the counter ends below n_chunks + #waves
+        // every wave stops at its first out-of-range ticket: the counter ends below n_chunks + #waves.
+        // Large batches take 16 codewords per ticket (keeps the same-address atomics off the critical
+        // path); small ones shrink the ticket so that all 4096 waves get work and the tail stays short.
+        const int chunk = int(std::max<size_t>(1, std::min<size_t>(kNpChunk, ncw / (size_t(grid) * kNpWaves * 4))));
         DTL_HIP_CHECK(hipMemsetAsync(np_queue_, 0, sizeof(unsigned int), stream));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_col_ptr_, np_perm_,
-                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, np_queue_);
+                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, np_queue_, chunk);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
     }
