@@ -7,6 +7,10 @@
 
 namespace dtl {
 
+// outputs per workgroup of the sync kernel; a continued stream re-joins its carried samples at a multiple
+// of this so that every timing-metric value is recomputed bit-identically
+constexpr int kSyncTileSamples = 4096;
+
 // edges / metric are produced for samples m_begin .. n-1 only (earlier samples are history of a stream
 // continued from a previous call); metric_out[m - m_begin]
 int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int fft_len, float threshold,

@@ -148,16 +148,32 @@ __device__ uint32_t crc_bits(const uint8_t* data, int len, int nbits, uint32_t p
 
 // ------------------------------------------------------------------------------------------
 // K1: Schmidl & Cox timing metric (GR ofdm_sync_sc_cfb as wired at ofdm_receiver.py:71-72).
-// A workgroup owns kSyncTile output samples.  It stages tile + N+1 samples of history in LDS,
-// forms c[j] = r[j] conj(r[j-N/2]) and e[j] = |r[j]|^2 in float (as the reference's multiply /
-// mag-squared blocks do), builds inclusive prefix sums of c and 0.5 e in DOUBLE with one block
-// scan, and reads every window sum as a difference of two prefixes:
-//   P[n] = -(S_c[n] - S_c[n-N/2]),  E[n] = S_e[n] - S_e[n-N],  metric = |P|^2 / E^2   (float).
+//   c[j] = r[j] conj(r[j-N/2]),  e[j] = |r[j]|^2      in float (the reference's multiply / mag-squared blocks)
+//   P[m] = -sum_{j in (m-N/2, m]} c[j],  E[m] = sum_{j in (m-N, m]} 0.5 e[j]   window sums in DOUBLE
+//   metric[m] = |P|^2 / E^2 (float), compared with the threshold
+// A 256-thread workgroup owns a tile of 4096 output samples.  The tile plus 1.5 N samples of history is
+// staged in LDS once (coalesced 8-byte loads; LDS rows padded by one element per 16 so that lane ==
+// strip is bank-conflict free).  Each thread owns a strip of 16 consecutive outputs:
+//   pass A  sums c / 0.5e over its strip (values stay in registers) -- the first N/16 lanes also sum
+//           one history strip each;
+//   scan    inclusive prefix over the strip totals (wave shuffles + 4 wave totals): the window sums
+//           just before a strip are differences of this COARSE prefix (3 doubles per 16 samples in
+//           LDS instead of 3 per sample);
+//   pass C  slides the three window sums along the strip (+ new term from registers, - old term
+//           recomputed from the staged samples), forms the metric, records the threshold flags.
 // Only the threshold crossings ("edges") leave the chip; plateau logic is sequential (host).
+// Without a metric output the test RN(num / den) >= thr is evaluated without the division: with
+// B = the rounding boundary between thr and its predecessor (25 significant bits), num >= B * den
+// is exact in double (49-bit product) and decides the same way for every finite den > 0.
 // ------------------------------------------------------------------------------------------
 constexpr int kSyncThreads = 256;
-constexpr int kSyncTile = 1024;
+constexpr int kSyncStrip = 16;
+constexpr int kSyncTile = kSyncThreads * kSyncStrip;
+static_assert(kSyncTile == kSyncTileSamples, "the stream carry is aligned to the sync tile");
 
+__device__ __forceinline__ int sync_pad(int j) { return j + (j >> 4); }
+
+template <bool WITH_METRIC>
 __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
                                                                  int64_t m_begin, int N, float thr,
                                                                  unsigned long long* __restrict__ edges,
@@ -166,67 +182,132 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
                                                                  float* __restrict__ metric_out)
 {
     extern __shared__ double sync_smem[];
+    constexpr int R = kSyncStrip;
     const int half = N / 2;
-    const int M = kSyncTile + N + 1;               // prefix arrays cover samples j0 .. j0+M-1
+    const int nh = N / R;                       // history strips in front of the tile
+    const int hw = half / R;                    // strips per P window
+    const int nS = nh + kSyncThreads;
+    const int n_raw = kSyncTile + N + half;     // staged samples: [t0 - N - half, t0 + tile)
     const int64_t t0 = (m_begin / kSyncTile + int64_t(blockIdx.x)) * kSyncTile; // tiles stay aligned to sample 0
-    const int64_t j0 = t0 - N - 1;
-    double* Sr = sync_smem;                        // prefix of c.re
-    double* Si = Sr + M;                           // prefix of c.im
-    double* Se = Si + M;                           // prefix of 0.5 * e
-    cf32* raw = reinterpret_cast<cf32*>(Se + M);   // samples j0-N/2 .. j0+M-1, coalesced staging
+    const int64_t b0 = t0 - N - half;
+    double* cp_r = sync_smem;                   // coarse inclusive prefix over strips, k = 0 .. nS-1
+    double* cp_i = cp_r + nS;
+    double* cp_e = cp_i + nS;
+    cf32* raw = reinterpret_cast<cf32*>(cp_e + nS);
     __shared__ double wave_tot[3][kSyncThreads / 64];
+    __shared__ double halo_tot[3];
+    __shared__ unsigned char last_flag[kSyncThreads];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int per = (M + kSyncThreads - 1) / kSyncThreads; // consecutive elements per thread
-    const int lo = tid * per, hi = min(M, lo + per);
-    for (int q = tid; q < M + half; q += kSyncThreads) {
-        const int64_t j = j0 - half + q;
+
+    for (int q = tid; q < n_raw; q += kSyncThreads) {
+        const int64_t j = b0 + q;
         cf32 v = { 0.0f, 0.0f };
         if (j >= 0 && j < n) v = iq[j];
-        raw[q] = v;
+        raw[sync_pad(q)] = v;
     }
     __syncthreads();
-    // thread-local inclusive prefix over its run of consecutive elements
-    double ar = 0, ai = 0, ae = 0;
-    for (int q = lo; q < hi; q++) {
-        const cf32 a = raw[q + half], b = raw[q];
-        const float cr = a.re * b.re + a.im * b.im, ci = a.im * b.re - a.re * b.im;
-        ar += double(cr); ai += double(ci);
-        ae += double(0.5f * (a.re * a.re + a.im * a.im));
-        Sr[q] = ar; Si[q] = ai; Se[q] = ae;
+
+    // ---- pass A: strip totals.  Sample j of the strip domain (which starts at t0 - N) is raw[half + j].
+    float cr[R], ci[R], eh[R];
+    double tr = 0, ti = 0, te = 0;
+    {
+        const int base = half + (nh + tid) * R;
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            const cf32 a = raw[sync_pad(base + s)], b = raw[sync_pad(base + s - half)];
+            cr[s] = a.re * b.re + a.im * b.im;
+            ci[s] = a.im * b.re - a.re * b.im;
+            eh[s] = 0.5f * (a.re * a.re + a.im * a.im);
+            tr += double(cr[s]); ti += double(ci[s]); te += double(eh[s]);
+        }
     }
-    // exclusive scan of the per-thread totals: wave shuffle scan + cross-wave fix-up
-    double xr = ar, xi = ai, xe = ae;
+    double hr = 0, hi = 0, he = 0; // history strip `tid` (wave 0 only: nh <= 64)
+    if (tid < nh) {
+        const int base = half + tid * R;
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            const cf32 a = raw[sync_pad(base + s)], b = raw[sync_pad(base + s - half)];
+            hr += double(a.re * b.re + a.im * b.im);
+            hi += double(a.im * b.re - a.re * b.im);
+            he += double(0.5f * (a.re * a.re + a.im * a.im));
+        }
+    }
+    // ---- scans (inclusive, fixed order)
+    if (wid == 0) {
+        for (int o = 1; o < 64; o <<= 1) {
+            const double a = __shfl_up(hr, o), b = __shfl_up(hi, o), c = __shfl_up(he, o);
+            if (lane >= o) { hr += a; hi += b; he += c; }
+        }
+        if (lane < nh) { cp_r[lane] = hr; cp_i[lane] = hi; cp_e[lane] = he; }
+        if (lane == nh - 1) { halo_tot[0] = hr; halo_tot[1] = hi; halo_tot[2] = he; }
+    }
+    double xr = tr, xi = ti, xe = te;
     for (int o = 1; o < 64; o <<= 1) {
-        const double tr = __shfl_up(xr, o), ti = __shfl_up(xi, o), te = __shfl_up(xe, o);
-        if (lane >= o) { xr += tr; xi += ti; xe += te; }
+        const double a = __shfl_up(xr, o), b = __shfl_up(xi, o), c = __shfl_up(xe, o);
+        if (lane >= o) { xr += a; xi += b; xe += c; }
     }
     if (lane == 63) { wave_tot[0][wid] = xr; wave_tot[1][wid] = xi; wave_tot[2][wid] = xe; }
     __syncthreads();
-    double br = xr - ar, bi = xi - ai, be = xe - ae;          // exclusive within the wave
-    for (int w = 0; w < wid; w++) { br += wave_tot[0][w]; bi += wave_tot[1][w]; be += wave_tot[2][w]; }
-    for (int q = lo; q < hi; q++) { Sr[q] += br; Si[q] += bi; Se[q] += be; }
+    {
+        double br = halo_tot[0], bi = halo_tot[1], be = halo_tot[2];
+        for (int w = 0; w < wid; w++) { br += wave_tot[0][w]; bi += wave_tot[1][w]; be += wave_tot[2][w]; }
+        cp_r[nh + tid] = br + xr; cp_i[nh + tid] = bi + xi; cp_e[nh + tid] = be + xe;
+    }
     __syncthreads();
-    // metric for samples m = t0-1 .. t0+tile-1 (index q = m - j0); thread owns tile/threads consecutive m
-    constexpr int kOut = kSyncTile / kSyncThreads;
-    const int q_first = N + 1 + tid * kOut;                   // q of the thread's first output sample
-    auto metric_at = [&](int q) -> float {
-        const float Pr = float(-(Sr[q] - Sr[q - half])), Pi = float(-(Si[q] - Si[q - half]));
-        const float E = float(Se[q] - Se[q - N]);
-        const float num = Pr * Pr + Pi * Pi;
-        return num / (E * E);
-    };
-    const int64_t m_first = t0 + int64_t(tid) * kOut;
-    if (m_first >= n) return;
-    bool prev = (m_first - 1 >= 0) ? (metric_at(q_first - 1) >= thr) : false;
-#pragma unroll
-    for (int s = 0; s < kOut; s++) {
-        const int64_t m = m_first + s;
-        if (m >= n) break;
-        const float mt = metric_at(q_first + s);
-        const bool cur = mt >= thr;
-        if (m >= m_begin) {
-            if (metric_out) metric_out[m - m_begin] = mt;
+
+    // ---- pass C: window sums just before the strip, then slide
+    const int km1 = nh + tid - 1;               // last strip in front of this thread's outputs (>= nh - 1 >= 3)
+    double Wr = cp_r[km1] - cp_r[km1 - hw];
+    double Wi = cp_i[km1] - cp_i[km1 - hw];
+    double We = cp_e[km1] - (tid > 0 ? cp_e[tid - 1] : 0.0);
+    // threshold test: exact division-free form (see the header comment) or the plain float quotient
+    const unsigned thr_bits = unsigned(__float_as_int(thr));
+    const bool exact_ok = thr > 1.17549435e-38f && thr < 3.0e38f;
+    const double bound = exact_ok ? 0.5 * (double(__int_as_float(int(thr_bits - 1))) + double(thr)) : 0.0;
+    const bool tie_up = (thr_bits & 1u) == 0;   // a quotient exactly on the boundary rounds to the even mantissa
+    auto above = [&](float num, float den) -> bool {
+        if (!WITH_METRIC && exact_ok && den > 0.0f && den < 3.0e38f && num < 3.0e38f) {
+            const double lhs = double(num), rhs = bound * double(den);
+            return tie_up ? lhs >= rhs : lhs > rhs;
         }
+        return num / den >= thr;
+    };
+    auto metric_parts = [&](float& num, float& den) {
+        const float Pr = float(-Wr), Pi = float(-Wi), E = float(We);
+        num = Pr * Pr + Pi * Pi;
+        den = E * E;
+    };
+    const int64_t m0 = t0 + int64_t(tid) * R;
+    bool prev0 = false;                         // flag of sample m0 - 1 as this tile sees it (lane 0 of the tile uses it)
+    if (tid == 0 && m0 - 1 >= 0) { float num, den; metric_parts(num, den); prev0 = above(num, den); }
+    unsigned flags = 0;
+    const int rb_new = N + half + tid * R;      // raw index of r[m0]
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        const cf32 oa = raw[sync_pad(rb_new + s - half)], ob = raw[sync_pad(rb_new + s - N)];
+        const float ocr = oa.re * ob.re + oa.im * ob.im, oci = oa.im * ob.re - oa.re * ob.im;
+        const float oeh = 0.5f * (ob.re * ob.re + ob.im * ob.im);
+        Wr = (Wr + double(cr[s])) - double(ocr);
+        Wi = (Wi + double(ci[s])) - double(oci);
+        We = (We + double(eh[s])) - double(oeh);
+        float num, den;
+        metric_parts(num, den);
+        if (WITH_METRIC) {
+            const int64_t m = m0 + s;
+            if (m >= m_begin && m < n) metric_out[m - m_begin] = num / den;
+        }
+        if (above(num, den)) flags |= 1u << s;
+    }
+    const int64_t m_last = min<int64_t>(m0 + R, n) - 1; // last valid output of the strip
+    last_flag[tid] = (m_last >= m0) ? ((flags >> int(m_last - m0)) & 1u) : 0;
+    __syncthreads();
+    bool prev = tid ? (last_flag[tid - 1] != 0) : prev0;
+    if (m0 >= n) return;
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        const int64_t m = m0 + s;
+        if (m >= n) break;
+        const bool cur = (flags >> s) & 1u;
         if (cur != prev && m >= m_begin) {
             const unsigned int slot = atomicAdd(n_edges, 1u);
             if (slot < max_edges) edges[slot] = (static_cast<unsigned long long>(m) << 1) | (cur ? 1ull : 0ull);
@@ -783,17 +864,24 @@ int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int N, float t
                       unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st)
 {
     if (m_begin < 0 || m_begin > n) return DTL_ERR_INVALID_ARG;
-    const size_t lds = size_t(kSyncTile + N + 1) * 3 * sizeof(double) + size_t(kSyncTile + N + 1 + N / 2) * sizeof(cf32);
+    if (N < 64 || (N % (2 * kSyncStrip)) != 0 || N / kSyncStrip > 64) return DTL_ERR_UNSUPPORTED; // history strips live in one wave
+    const int n_raw = kSyncTile + N + N / 2;
+    const size_t lds = size_t(N / kSyncStrip + kSyncThreads) * 3 * sizeof(double) + size_t(n_raw + n_raw / 16 + 2) * sizeof(cf32);
     const int64_t grid = (n + kSyncTile - 1) / kSyncTile - m_begin / kSyncTile;
     if (grid <= 0) return DTL_OK;
-    static size_t attr_lds = 64 * 1024;
-    if (lds > attr_lds) {
-        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sync_edges_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_lds = lds;
+    static size_t attr_lds[2] = { 64 * 1024, 64 * 1024 };
+    const int which = metric_out ? 1 : 0;
+    const void* fn = which ? reinterpret_cast<const void*>(sync_edges_kernel<true>) : reinterpret_cast<const void*>(sync_edges_kernel<false>);
+    if (lds > attr_lds[which]) {
+        DTL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_lds[which] = lds;
     }
-    hipLaunchKernelGGL(sync_edges_kernel, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, m_begin, N, thr,
-                       edges, n_edges, max_edges, metric_out);
+    if (metric_out)
+        hipLaunchKernelGGL(sync_edges_kernel<true>, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, m_begin, N, thr,
+                           edges, n_edges, max_edges, metric_out);
+    else
+        hipLaunchKernelGGL(sync_edges_kernel<false>, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, m_begin, N, thr,
+                           edges, n_edges, max_edges, metric_out);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

@@ -1092,8 +1092,11 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
             keep = E - max_carry;
             pf.erase(std::remove_if(pf.begin(), pf.end(), [&](int64_t t) { return t - P < keep; }), pf.end());
         }
+        // the tile of the sync kernel that contains the next new sample must see real history, not the
+        // zero fill of a buffer start: then every metric value equals the one a single batch computes
+        keep = std::min(keep, (E & ~int64_t(kSyncTileSamples - 1)) - N - N / 2);
         keep = std::max<int64_t>(std::max<int64_t>(keep, A), 0);
-        keep &= ~int64_t(1023);
+        keep &= ~int64_t(kSyncTileSamples - 1);
         const int64_t len = E - keep;
         DTL_TRY(d_carry_.ensure(std::max<size_t>(size_t(len), 1) * sizeof(cf32)));
         if (len) DTL_HIP_CHECK(hipMemcpyAsync(d_carry_.p, iq + (keep - A), size_t(len) * sizeof(cf32), hipMemcpyDeviceToDevice, st));
