@@ -474,9 +474,9 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 // than 2^-49 (relative) to a rounding boundary of the float format, so the result IS the correctly
 // rounded IEEE quotient (3 full-rate instructions instead of the ~11 of v_div_scale/rcp/fma/fixup);
 // quotients in the subnormal range all map to exp() == 1.  tools/math_check.hip checks both claims.
-template <int BPS>
+template <int BPS, bool PLAIN_DIST>
 __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, double neg_inv_npwr,
-                                                  int dist_mode, float* __restrict__ o)
+                                                  float* __restrict__ o)
 {
     constexpr int M = 1 << BPS;
     float p0[BPS], p1[BPS];
@@ -488,7 +488,8 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const float dr = s.re - lp[m].re, di = s.im - lp[m].im;
-        const float dist = dist_mode ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
+        // compile-time switch: a runtime select would evaluate the correctly rounded sqrtf for every point
+        const float dist = PLAIN_DIST ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
         const float d = dm_exp(float(double(dist) * neg_inv_npwr)); // fixed-sequence expf (dtl_math.h)
 #pragma unroll
         for (int j = 0; j < BPS; j++) {
@@ -569,33 +570,36 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
         const bool is_pilot = t.n_pilot_sets && t.pilot_mask[pilot_carr_set * N + k];
         const cf32 y = frame[i * N + k];
         cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
-        if (is_pilot) {
-            const cf32 pv = t.pilot_val[pset * N + k];
-            const cf32 pilot_eq = cdiv(y, Hk);
-            // mpsk_snr_est_simple::update on |pilot_eq| (Welford, double)
-            const double x = double(sqrtf(pilot_eq.re * pilot_eq.re + pilot_eq.im * pilot_eq.im));
-            w.n += 1.0;
-            const double d = x - w.mean;
-            w.mean += d / w.n;
-            w.m2 += d * (x - w.mean);
-            Hk = cadd(cscale(alpha, Hk), cdiv(cscale(1 - alpha, y), pv));
-            hard_v = pv;
-        } else if (occupied) {
-            const cf32 sym_eq = cdiv(y, Hk);
-            unsigned idx;
-            switch (fd.cnst) { // decision_maker of each GR constellation
-            case 1: idx = sym_eq.re > 0; break;
-            case 2: idx = 2 * (sym_eq.im > 0) + (sym_eq.re > 0); break;
-            case 3: idx = (fabsf(sym_eq.re) <= fabsf(sym_eq.im) ? 4u : 0u) | (sym_eq.re <= 0 ? 1u : 0u) | (sym_eq.im <= 0 ? 2u : 0u); break;
-            default: {
-                const float level = sqrtf(0.1f);
-                idx = (sym_eq.im > 0 ? 8u : 0u) | (sym_eq.re < 0 ? 4u : 0u) | (fabsf(sym_eq.re) > 2 * level ? 2u : 0u) | (fabsf(sym_eq.im) > 2 * level ? 1u : 0u);
-            } break;
+        // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
+        // tap towards y / (known or decided symbol) -- so the two cases share one pair of complex divisions
+        // (lanes of one wave hold both kinds; separate branches would execute both pairs)
+        if (is_pilot || occupied) {
+            const cf32 eqv = cdiv(y, Hk);
+            cf32 ref;
+            if (is_pilot) {
+                ref = t.pilot_val[pset * N + k];
+                // mpsk_snr_est_simple::update on |pilot_eq| (Welford, double)
+                const double x = double(sqrtf(eqv.re * eqv.re + eqv.im * eqv.im));
+                w.n += 1.0;
+                const double d = x - w.mean;
+                w.mean += d / w.n;
+                w.m2 += d * (x - w.mean);
+            } else {
+                unsigned idx;
+                switch (fd.cnst) { // decision_maker of each GR constellation
+                case 1: idx = eqv.re > 0; break;
+                case 2: idx = 2 * (eqv.im > 0) + (eqv.re > 0); break;
+                case 3: idx = (fabsf(eqv.re) <= fabsf(eqv.im) ? 4u : 0u) | (eqv.re <= 0 ? 1u : 0u) | (eqv.im <= 0 ? 2u : 0u); break;
+                default: {
+                    const float level = sqrtf(0.1f);
+                    idx = (eqv.im > 0 ? 8u : 0u) | (eqv.re < 0 ? 4u : 0u) | (fabsf(eqv.re) > 2 * level ? 2u : 0u) | (fabsf(eqv.im) > 2 * level ? 1u : 0u);
+                } break;
+                }
+                ref = pts[idx];
+                soft_v = eqv;
             }
-            const cf32 sym_est = pts[idx];
-            Hk = cadd(cscale(alpha, Hk), cdiv(cscale(1 - alpha, y), sym_est));
-            hard_v = sym_est;
-            soft_v = sym_eq;
+            Hk = cadd(cscale(alpha, Hk), cdiv(cscale(1 - alpha, y), ref));
+            hard_v = ref;
         }
         if (hard_row) hard_row[i * N + k] = hard_v;
         if (soft_row) soft_row[i * N + k] = soft_v;
@@ -631,11 +635,20 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
         if (soft_syms) soft_syms[size_t(blockIdx.x) * t.frame_capacity + q] = s;
         if (t.has_fec) {
             float* o = llr_out + size_t(llr_off[blockIdx.x]) + size_t(q) * bps;
-            switch (bps) {
-            case 1: soft_demap_symbol<1>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
-            case 2: soft_demap_symbol<2>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
-            case 3: soft_demap_symbol<3>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
-            default: soft_demap_symbol<4>(s, pts, neg_inv_npwr, t.llr_dist_mode, o); break;
+            if (t.llr_dist_mode) {
+                switch (bps) {
+                case 1: soft_demap_symbol<1, true>(s, pts, neg_inv_npwr, o); break;
+                case 2: soft_demap_symbol<2, true>(s, pts, neg_inv_npwr, o); break;
+                case 3: soft_demap_symbol<3, true>(s, pts, neg_inv_npwr, o); break;
+                default: soft_demap_symbol<4, true>(s, pts, neg_inv_npwr, o); break;
+                }
+            } else {
+                switch (bps) {
+                case 1: soft_demap_symbol<1, false>(s, pts, neg_inv_npwr, o); break;
+                case 2: soft_demap_symbol<2, false>(s, pts, neg_inv_npwr, o); break;
+                case 3: soft_demap_symbol<3, false>(s, pts, neg_inv_npwr, o); break;
+                default: soft_demap_symbol<4, false>(s, pts, neg_inv_npwr, o); break;
+                }
             }
         }
     };

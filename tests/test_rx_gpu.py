@@ -124,6 +124,18 @@ def test_fec_chain_matches_oracle_64(oracle, dtl, cuda, cnst, esn0, nbytes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cnst,esn0", [(2, 14.0), (3, 22.0), (4, 25.0)])
+def test_plain_distance_llr_mode(oracle, dtl, cuda, cnst, esn0):
+    """llr_dist_mode=1: the demapper's metric is the plain distance (sqrtf) instead of its square (the other
+    reading of calc_soft_dec); a separate template instance of the demapper."""
+    pcfg, ocfg, code = make_pair(oracle, dtl, llr_dist_mode=1)
+    user, hdrs, x = make_stream(oracle, ocfg, code, cnst, 5000, esn0, seed=300 + cnst)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
+    assert ref["n_frames"] >= 0.9 * len(hdrs)
+    _compare(rx, res, ref, ocfg, True)
+
+
+@pytest.mark.gpu
 def test_no_fec_chain_matches_oracle(oracle, dtl, cuda):
     """config #1: 64-pt FFT, BPSK, no FEC (plumbing)."""
     pcfg, ocfg, code = make_pair(oracle, dtl, fec=None)

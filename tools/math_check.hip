@@ -1,6 +1,9 @@
-// Exhaustive check (all 2^32 float bit patterns): dm_exp's scaling tail `ldexpf(p, k)` (one v_ldexp_f32)
-// is bit-identical to the two-step power-of-two scaling `(p * 2^(k/2)) * 2^(k - k/2)` the test oracle
-// executes on the CPU (oracle/orc_math.h).  Prints the number of mismatching inputs (expected 0).
+// Exhaustive checks (all 2^32 float bit patterns) that the kernel-side forms of dtl_math.h return the bits of
+// the plain forms the test oracle executes on the CPU (oracle/orc_math.h):
+//   dm_exp: branch-free, scaling tail `ldexpf(p, k)` (one v_ldexp_f32)  vs  early returns + two-step
+//           power-of-two scaling `(p * 2^(k/2)) * 2^(k - k/2)`;
+//   dm_log: branch-free, division without v_div_scale / v_div_fixup     vs  early returns + IEEE division;
+// plus the demapper's exact-reciprocal quotient on random operand pairs.  Prints mismatch counts (expected 0).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -27,6 +30,42 @@ __device__ __forceinline__ float exp_two_step(float x)
     const int k1 = k / 2, k2 = k - k1;
     const float s1 = __int_as_float((k1 + 127) << 23), s2 = __int_as_float((k2 + 127) << 23);
     return (p * s1) * s2;
+}
+
+// the early-return form with a plain IEEE division: what oracle/orc_math.h executes on the CPU
+__device__ float log_plain(float x)
+{
+    if (x != x) return x;
+    if (x < 0.0f) return __int_as_float(0x7fc00000);
+    if (x == 0.0f) return __int_as_float(0xff800000);
+    if (x == __int_as_float(0x7f800000)) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x = x * 33554432.0f; e = -25; }
+    unsigned ix = unsigned(__float_as_int(x));
+    e += int(ix >> 23) - 127;
+    ix = (ix & 0x007fffffu) | 0x3f800000u;
+    float m = __int_as_float(int(ix));
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float R = z * (0.66666662693f + z * (0.40000972152f + z * (0.28498786688f + z * 0.24279078841f)));
+    const float hfsq = 0.5f * f * f;
+    const float ef = float(e);
+    return ef * 6.9313812256e-01f + (f - (hfsq - (s * (hfsq + R) + ef * 9.0580006145e-06f)));
+}
+
+__global__ void check_log(unsigned long long* mism, unsigned* example)
+{
+    const uint64_t tid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0;
+    for (uint64_t u = tid; u < (1ull << 32); u += uint64_t(gridDim.x) * blockDim.x) {
+        const float x = __int_as_float(int(unsigned(u)));
+        const float a = log_plain(x), b = dtl::dm_log(x);
+        const bool same = (__float_as_int(a) == __float_as_int(b)) || (a != a && b != b);
+        if (!same) { bad++; example[0] = unsigned(u); }
+    }
+    if (bad) atomicAdd(mism, bad);
 }
 
 __global__ void check(unsigned long long* mism, unsigned* example)
@@ -82,6 +121,12 @@ int main()
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&hex_, ex, 4, hipMemcpyDeviceToHost);
     printf("dm_exp ldexp tail vs two-step scaling: %llu mismatches over 2^32 inputs (last example bits 0x%08x)\n", h, hex_);
+    (void)hipMemset(d, 0, 8); (void)hipMemset(ex, 0, 4);
+    hipLaunchKernelGGL(check_log, dim3(4096), dim3(256), 0, 0, d, ex);
+    (void)hipDeviceSynchronize();
+    unsigned long long hl = 0;
+    (void)hipMemcpy(&hl, d, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&hex_, ex, 4, hipMemcpyDeviceToHost);
+    printf("dm_log (branch-free, in-range division) vs early-return form with IEEE division: %llu mismatches over 2^32 inputs (last example bits 0x%08x)\n", hl, hex_);
     unsigned long long *d2, h2[2] = { 0, 0 };
     unsigned *ex2, hex2[2] = { 0, 0 };
     (void)hipMalloc(&d2, 16); (void)hipMalloc(&ex2, 8);
@@ -91,5 +136,5 @@ int main()
     (void)hipMemcpy(h2, d2, 16, hipMemcpyDeviceToHost); (void)hipMemcpy(hex2, ex2, 8, hipMemcpyDeviceToHost);
     printf("float(double(a) * (-1/b)) vs -a/b: %llu mismatches over %llu operand pairs (example a=0x%08x b=0x%08x)\n",
            h2[0], h2[1], hex2[0], hex2[1]);
-    return (h != 0) || (h2[0] != 0);
+    return (h != 0) || (h2[0] != 0) || (hl != 0);
 }
