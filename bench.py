@@ -100,6 +100,12 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on fd 1) and any
+    # stray print are sent to stderr; the result goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import gr_dtl_amd as dtl
 
@@ -111,7 +117,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("DTL_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path with one rank
+    if world > 1 or (force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
@@ -196,7 +203,8 @@ def main():
             nfs = min(nfs, n_frames)
             ns = 100 + nfs * rx.frame_samples + rx.frame_samples // 2
             out["cpu_baseline"] = cpu_baseline(cfg, w, x[:ns].cpu().numpy(), nfs)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,7 +29,7 @@ def combine(elapsed_s, counters, dist=None, device=None):
     import torch
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     c = torch.tensor([float(v) for v in counters], dtype=torch.float64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), [float(v) for v in c.tolist()]
