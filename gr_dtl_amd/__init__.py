@@ -9,3 +9,5 @@ from .ofdm_adaptive_config import (constellation_type_t, get_bits_per_symbol, ma
                                    make_scaled_rx_config, make_tx_config, ofdm_adaptive_config,
                                    ofdm_adaptive_rx_config, ofdm_adaptive_tx_config)
 from .ofdm_receiver import ofdm_adaptive_rx, ofdm_receiver  # noqa: F401
+from .frame_file_store import ber_report, frame_file_store, read_frames, store_rx_frames, store_tx_frames  # noqa: F401
+from .monitor import monitor_probe  # noqa: F401

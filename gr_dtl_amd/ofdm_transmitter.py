@@ -137,7 +137,7 @@ class ofdm_transmitter:
         cws = enc.encode_batch(data)
         return np.concatenate([np.concatenate([cws[i, :n - k], cws[i, n - k:n - k + ks[i]]]) for i in range(ncws)])
 
-    def build_fec_frames(self, user_bytes, constellation, fec_scheme, first_frame_no=0):
+    def build_fec_frames(self, user_bytes, constellation, fec_scheme, first_frame_no=0, first_tb_no=0):
         """-> (symbols uint8 [n_frames, capacity], [header field dicts])"""
         user = np.asarray(user_bytes, dtype=np.uint8)
         cnst = int(constellation)
@@ -152,7 +152,7 @@ class ofdm_transmitter:
             raise RuntimeError("Misconfiguration: TB should be able to carry at least 1 user data bit")
         frames, hdrs = [], []
         cur = np.zeros(cap, dtype=np.uint8)
-        st = dict(offset=0, used=0, payload=0, wpos=0, frame_no=first_frame_no, tb_count=0, tb_bits=0)
+        st = dict(offset=0, used=0, payload=0, wpos=0, frame_no=first_frame_no, tb_count=first_tb_no, tb_bits=0)
 
         def emit(payload_bytes):
             nonlocal cur
@@ -250,9 +250,9 @@ class ofdm_transmitter:
         out = np.concatenate([time[..., N - cp:], time], axis=-1).astype(np.complex64)
         return out.reshape(nfr, -1)
 
-    def work(self, user_bytes, constellation, fec_scheme=None, first_frame_no=0):
+    def work(self, user_bytes, constellation, fec_scheme=None, first_frame_no=0, first_tb_no=0):
         if self.fec:
-            syms, hdrs = self.build_fec_frames(user_bytes, constellation, fec_scheme, first_frame_no)
+            syms, hdrs = self.build_fec_frames(user_bytes, constellation, fec_scheme, first_frame_no, first_tb_no)
         else:
             syms, hdrs = self.build_nofec_frames(user_bytes, constellation, first_frame_no)
         return self.modulate(syms, hdrs), hdrs
@@ -274,5 +274,5 @@ class ofdm_adaptive_tx:
         self.config = config
         self.direct_tx = ofdm_transmitter(config)
 
-    def work(self, user_bytes, constellation, fec_scheme=None):
-        return self.direct_tx.work(user_bytes, constellation, fec_scheme)
+    def work(self, user_bytes, constellation, fec_scheme=None, first_frame_no=0, first_tb_no=0):
+        return self.direct_tx.work(user_bytes, constellation, fec_scheme, first_frame_no, first_tb_no)
