@@ -4,6 +4,7 @@
 #include "dtl_common.h"
 #include "ldpc_bp.h"
 #include "rx_pipeline.h"
+#include "tx_pipeline.h"
 
 #include <algorithm>
 #include <cstring>
@@ -28,9 +29,14 @@ struct dtl_rx {
     dtl::Receiver rx;
 };
 
+struct dtl_tx {
+    dtl::Transmitter tx;
+};
+
 static_assert(sizeof(dtl_cw_desc) == sizeof(dtl::CwDesc), "C ABI gather descriptor layout");
 static_assert(sizeof(dtl_rx_frame_info) == sizeof(dtl::FrameInfo), "C ABI frame info layout");
 static_assert(sizeof(dtl_rx_tb_info) == sizeof(dtl::TbInfo), "C ABI TB info layout");
+static_assert(sizeof(dtl_tx_frame_info) == sizeof(dtl::TxFrameInfo), "C ABI TX frame info layout");
 
 extern "C" {
 
@@ -129,17 +135,12 @@ int dtl_ldpc_decode_batch(const dtl_ldpc* h, const float* d_llr, size_t ncw, uin
 }
 
 
-int dtl_rx_create(const dtl_rx_cfg* c, dtl_rx** out)
+static int fill_config(const dtl_rx_cfg* c, dtl::RxConfig& g, const char* who)
 {
-    if (!c || !out) { dtl::set_last_error("rx_create: null argument"); return DTL_ERR_INVALID_ARG; }
-    *out = nullptr;
     if (c->fft_len <= 0 || c->n_occ_sets <= 0 || !c->occ || !c->occ_len || !c->sync_word1 || !c->sync_word2) {
-        dtl::set_last_error("rx_create: incomplete configuration");
+        dtl::set_last_error(std::string(who) + ": incomplete configuration");
         return DTL_ERR_INVALID_ARG;
     }
-    auto* h = new (std::nothrow) dtl_rx();
-    if (!h) return DTL_ERR_CAPACITY;
-    dtl::RxConfig& g = h->rx.cfg;
     g.fft_len = c->fft_len; g.cp_len = c->cp_len; g.frame_length = c->frame_length; g.has_fec = c->has_fec != 0;
     for (int s = 0; s < c->n_occ_sets; s++)
         g.occupied_carriers.emplace_back(c->occ + size_t(s) * c->max_occ, c->occ + size_t(s) * c->max_occ + c->occ_len[s]);
@@ -161,9 +162,58 @@ int dtl_rx_create(const dtl_rx_cfg* c, dtl_rx** out)
     for (int i = 0; i < c->n_fec_codes; i++) g.alist_texts.emplace_back(c->alist_texts[i], c->alist_lens[i]);
     for (int i = 0; i < c->n_mcs; i++) g.mcs.push_back({ c->mcs_snr[i], c->mcs_cnst[i], c->mcs_fec[i] });
     g.initial_mcs = c->initial_mcs; g.hysteresis = c->hysteresis; g.decision_th = c->decision_th > 0 ? c->decision_th : 5;
-    int rc = h->rx.init();
+    return DTL_OK;
+}
+
+int dtl_rx_create(const dtl_rx_cfg* c, dtl_rx** out)
+{
+    if (!c || !out) { dtl::set_last_error("rx_create: null argument"); return DTL_ERR_INVALID_ARG; }
+    *out = nullptr;
+    auto* h = new (std::nothrow) dtl_rx();
+    if (!h) return DTL_ERR_CAPACITY;
+    int rc = fill_config(c, h->rx.cfg, "rx_create");
+    if (rc == DTL_OK) rc = h->rx.init();
     if (rc != DTL_OK) { delete h; return rc; }
     *out = h;
+    return DTL_OK;
+}
+
+int dtl_tx_create(const dtl_rx_cfg* c, dtl_tx** out)
+{
+    if (!c || !out) { dtl::set_last_error("tx_create: null argument"); return DTL_ERR_INVALID_ARG; }
+    *out = nullptr;
+    auto* h = new (std::nothrow) dtl_tx();
+    if (!h) return DTL_ERR_CAPACITY;
+    int rc = fill_config(c, h->tx.cfg, "tx_create");
+    if (rc == DTL_OK) rc = h->tx.init();
+    if (rc != DTL_OK) { delete h; return rc; }
+    *out = h;
+    return DTL_OK;
+}
+
+void dtl_tx_destroy(dtl_tx* h) { delete h; }
+
+int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t constellation, int32_t fec,
+                   int32_t first_frame_no, int32_t first_tb_no, int32_t gap, int32_t want_syms, void* stream,
+                   dtl_tx_result* out)
+{
+    if (!h || !out) { dtl::set_last_error("tx_process: null argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    dtl::Transmitter& t = h->tx;
+    int rc = t.process(d_user, n_user, constellation, fec, first_frame_no, first_tb_no, gap, want_syms != 0,
+                       static_cast<hipStream_t>(stream));
+    if (rc != DTL_OK) return rc;
+    std::memset(out, 0, sizeof(*out));
+    out->n_frames = int64_t(t.frames.size());
+    out->n_samples = t.n_samples;
+    out->n_tbs = t.n_tbs;
+    out->frames = reinterpret_cast<const dtl_tx_frame_info*>(t.frames.data());
+    out->d_iq = t.d_iq.as<float>();
+    out->d_syms = want_syms ? t.d_syms.as<uint8_t>() : nullptr;
+    out->d_hdr_bits = t.d_hdr_bits.as<uint8_t>();
+    out->frame_capacity = t.frame_capacity();
+    out->hdr_bits = t.hdr_bits();
+    out->frame_samples = t.frame_samples();
     return DTL_OK;
 }
 

@@ -30,6 +30,61 @@ class _Cfg(C.Structure):
                 ("initial_mcs", C.c_int32), ("decision_th", C.c_int32), ("hysteresis", C.c_double)]
 
 
+def make_cfg_struct(cfg):
+    """ofdm_adaptive_{rx,tx}_config -> the flattened dtl_rx_cfg of the C ABI (+ the arrays it points to)."""
+    fec = len(cfg.fec_codes)
+    codes_alist, codes_id = [], {}
+    if fec:
+        codes_alist = list(zip(*cfg.fec_codes))[1]
+        codes_id = {name: id + 1 for (id, name) in enumerate(list(zip(*cfg.fec_codes))[0])}
+    mcs = [(snr_th, (cnst, codes_id.get(code_name, 0))) for (snr_th, (cnst, code_name)) in cfg.mcs]
+    occ_len = np.array([len(o) for o in cfg.occupied_carriers], dtype=np.int32)
+    max_occ = int(occ_len.max())
+    occ = np.zeros((len(cfg.occupied_carriers), max_occ), dtype=np.int32)
+    for i, o in enumerate(cfg.occupied_carriers):
+        occ[i, :len(o)] = o
+    pil = np.ascontiguousarray(cfg.pilot_carriers, dtype=np.int32)
+    psym = np.ascontiguousarray(np.asarray(cfg.pilot_symbols, dtype=np.complex64))
+    sw1 = np.ascontiguousarray(np.asarray(cfg.sync_word1, dtype=np.complex64))
+    sw2 = np.ascontiguousarray(np.asarray(cfg.sync_word2, dtype=np.complex64))
+    texts = []
+    for path in codes_alist:
+        with open(_resolve(path), "rb") as f:
+            texts.append(f.read())
+    n_codes = len(texts)
+    arr_texts = (C.c_char_p * max(n_codes, 1))(*texts) if n_codes else (C.c_char_p * 1)()
+    arr_lens = (C.c_size_t * max(n_codes, 1))(*[len(t) for t in texts]) if n_codes else (C.c_size_t * 1)()
+    mcs_snr = np.array([float(m[0]) for m in mcs], dtype=np.float64)
+    mcs_cnst = np.array([int(m[1][0]) for m in mcs], dtype=np.int32)
+    mcs_fec = np.array([int(m[1][1]) for m in mcs], dtype=np.int32)
+    c = _Cfg()
+    c.fft_len, c.cp_len, c.frame_length, c.has_fec = cfg.fft_len, cfg.cp_len, cfg.frame_length, int(bool(fec))
+    c.n_occ_sets, c.max_occ = occ.shape
+    c.occ_len, c.occ = occ_len.ctypes.data, occ.ctypes.data
+    c.n_pilot_sets, c.n_pilots = pil.shape
+    c.pilot_carriers = pil.ctypes.data
+    c.n_pilot_sym_sets = psym.shape[0]
+    c.pilot_symbols = psym.ctypes.data
+    c.sync_word1, c.sync_word2 = sw1.ctypes.data, sw2.ctypes.data
+    c.sync_threshold = float(getattr(cfg, "sync_threshold", 0.95))
+    c.eq_alpha = 0.1                      # ofdm_receiver.py:163
+    c.use_sync_correct = int(bool(getattr(cfg, "use_sync_correct", True)))
+    c.scramble_header = int(bool(cfg.scramble_bits))
+    c.llr_dist_mode = int(getattr(cfg, "llr_dist_mode", 0))
+    c.max_iterations = int(getattr(cfg, "ldpc_max_iterations", 15))
+    c.bp_sigma = float(getattr(cfg, "ldpc_sigma", 0.0))
+    c.n_fec_codes = n_codes
+    c.alist_texts = arr_texts
+    c.alist_lens = arr_lens
+    c.n_mcs = len(mcs)
+    c.mcs_snr, c.mcs_cnst, c.mcs_fec = mcs_snr.ctypes.data, mcs_cnst.ctypes.data, mcs_fec.ctypes.data
+    c.initial_mcs = int(getattr(cfg, "initial_mcs_id", 0))
+    c.decision_th = 5                     # ofdm_receiver.py:167
+    c.hysteresis = 1.0
+    keep = (occ_len, occ, pil, psym, sw1, sw2, arr_texts, arr_lens, mcs_snr, mcs_cnst, mcs_fec, texts)
+    return c, keep
+
+
 class FrameInfo(C.Structure):
     _fields_ = [("trigger", C.c_int64), ("header_ok", C.c_int32), ("carr_offset", C.c_int32),
                 ("payload_len", C.c_int32), ("frame_no", C.c_int32), ("cnst", C.c_int32), ("fb_cnst", C.c_int32),
@@ -129,53 +184,9 @@ class ofdm_receiver:
     def _setup(self):
         L = _lib.lib()
         self._declare(L)
-        cfg = self._config
         self.header_len = 2 if self.fec else 1  # ofdm_receiver.py:66-68
         self.frame_capacity = ofdm_adaptive.frame_capacity(self.frame_length, self.occupied_carriers)
-        occ_len = np.array([len(o) for o in self.occupied_carriers], dtype=np.int32)
-        max_occ = int(occ_len.max())
-        occ = np.zeros((len(self.occupied_carriers), max_occ), dtype=np.int32)
-        for i, o in enumerate(self.occupied_carriers):
-            occ[i, :len(o)] = o
-        pil = np.ascontiguousarray(self.pilot_carriers, dtype=np.int32)
-        psym = np.ascontiguousarray(np.asarray(self.pilot_symbols, dtype=np.complex64))
-        sw1 = np.ascontiguousarray(np.asarray(self.sync_words[0], dtype=np.complex64))
-        sw2 = np.ascontiguousarray(np.asarray(self.sync_words[1], dtype=np.complex64))
-        texts = []
-        for path in self.codes_alist:
-            with open(_resolve(path), "rb") as f:
-                texts.append(f.read())
-        n_codes = len(texts)
-        arr_texts = (C.c_char_p * max(n_codes, 1))(*texts) if n_codes else (C.c_char_p * 1)()
-        arr_lens = (C.c_size_t * max(n_codes, 1))(*[len(t) for t in texts]) if n_codes else (C.c_size_t * 1)()
-        mcs_snr = np.array([float(m[0]) for m in self.mcs], dtype=np.float64)
-        mcs_cnst = np.array([int(m[1][0]) for m in self.mcs], dtype=np.int32)
-        mcs_fec = np.array([int(m[1][1]) for m in self.mcs], dtype=np.int32)
-        c = _Cfg()
-        c.fft_len, c.cp_len, c.frame_length, c.has_fec = self.fft_len, self.cp_len, self.frame_length, int(bool(self.fec))
-        c.n_occ_sets, c.max_occ = occ.shape
-        c.occ_len, c.occ = occ_len.ctypes.data, occ.ctypes.data
-        c.n_pilot_sets, c.n_pilots = pil.shape
-        c.pilot_carriers = pil.ctypes.data
-        c.n_pilot_sym_sets = psym.shape[0]
-        c.pilot_symbols = psym.ctypes.data
-        c.sync_word1, c.sync_word2 = sw1.ctypes.data, sw2.ctypes.data
-        c.sync_threshold = float(self.sync_threshold)
-        c.eq_alpha = 0.1                      # ofdm_receiver.py:163
-        c.use_sync_correct = int(bool(self.use_sync_correct))
-        c.scramble_header = int(bool(self.scramble_bits))
-        c.llr_dist_mode = int(getattr(cfg, "llr_dist_mode", 0))
-        c.max_iterations = int(getattr(cfg, "ldpc_max_iterations", 15))
-        c.bp_sigma = float(getattr(cfg, "ldpc_sigma", 0.0))
-        c.n_fec_codes = n_codes
-        c.alist_texts = arr_texts
-        c.alist_lens = arr_lens
-        c.n_mcs = len(self.mcs)
-        c.mcs_snr, c.mcs_cnst, c.mcs_fec = mcs_snr.ctypes.data, mcs_cnst.ctypes.data, mcs_fec.ctypes.data
-        c.initial_mcs = int(self.initial_mcs_id)
-        c.decision_th = 5                     # ofdm_receiver.py:167
-        c.hysteresis = 1.0
-        self._keep = (occ_len, occ, pil, psym, sw1, sw2, arr_texts, arr_lens, mcs_snr, mcs_cnst, mcs_fec, texts)
+        c, self._keep = make_cfg_struct(self._config)
         _lib.check(L.dtl_rx_create(C.byref(c), C.byref(self._h)))
 
     @staticmethod

@@ -1,4 +1,8 @@
-"""Batched adaptive-OFDM transmitter (host side, numpy) -- the synthetic-frame generator.
+"""Batched adaptive-OFDM transmitter -- the synthetic-frame generator.
+
+Two implementations of the same graph behind one class: `work()` (host, numpy) and `work_device()` (HIP
+kernels behind dtl_tx_* of the C ABI: framing state machine on lengths on the host, CRC-32 / LDPC encoding /
+mapping / allocation / IFFT / cyclic prefix on the GPU; frames are bit-identical to the CPU oracle's TX).
 
 Mirrors the TX graph of python/dtl/ofdm_transmitter.py:63-189 for one large PDU and a constant MCS:
 ofdm_adaptive_fec_frame_bvb (lib/dtl/ofdm_adaptive_fec_frame_bvb_impl.cc:284-565) or
@@ -7,6 +11,7 @@ ofdm_adaptive_frame_bb (lib/dtl/ofdm_adaptive_frame_bb_impl.cc:131-163), ofdm_ad
 fft_vcc(inverse, shift), ofdm_cyclic_prefixer.  It is not on the accelerated path (SURVEY.md 8f rank 1);
 it exists so that benchmarks and examples can produce on-air frames without the test oracle.
 """
+import ctypes as C
 import zlib
 
 import numpy as np
@@ -98,6 +103,7 @@ class ofdm_transmitter:
 
     def __init__(self, config, name="tx"):
         self.name = name
+        self._config = config
         self.fft_len, self.cp_len = config.fft_len, config.cp_len
         self.occupied_carriers = config.occupied_carriers
         self.pilot_carriers = config.pilot_carriers
@@ -256,6 +262,86 @@ class ofdm_transmitter:
         else:
             syms, hdrs = self.build_nofec_frames(user_bytes, constellation, first_frame_no)
         return self.modulate(syms, hdrs), hdrs
+
+
+    # -- HIP path ---------------------------------------------------------------------------
+    def _device_handle(self):
+        if getattr(self, "_h", None):
+            return self._h
+        from . import _lib
+        from .ofdm_receiver import make_cfg_struct
+        L = _lib.lib()
+        if not getattr(L, "_tx_declared", False):
+            L.dtl_tx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+            L.dtl_tx_destroy.argtypes = [C.c_void_p]
+            L.dtl_tx_destroy.restype = None
+            L.dtl_tx_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_void_p, C.POINTER(_TxResult)]
+            L.dtl_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+            L._tx_declared = True
+        c, self._keep = make_cfg_struct(self._config)
+        h = C.c_void_p()
+        _lib.check(L.dtl_tx_create(C.byref(c), C.byref(h)))
+        self._h = h
+        return h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                from . import _lib
+                _lib.lib().dtl_tx_destroy(self._h)
+        except Exception:
+            pass
+
+    def work_device(self, user, constellation, fec_scheme=None, first_frame_no=0, first_tb_no=0, gap=0,
+                    want_syms=False):
+        """user: uint8 CUDA tensor.  -> (iq complex64 CUDA tensor [n_frames, frame_samples + gap], header records
+        (numpy structured array), symbol indices uint8 [n_frames, capacity] or None)"""
+        import torch
+        from . import _lib
+        if not (hasattr(user, "is_cuda") and user.is_cuda):
+            raise _lib.DtlError(_lib.ERR_NO_DEVICE, "ofdm_transmitter.work_device needs a device tensor (no CPU fallback)")
+        if user.dtype != torch.uint8:
+            raise ValueError("user bytes must be uint8")
+        user = user.contiguous().view(-1)
+        fec_idx = 0
+        if self.fec:
+            fec_idx = self.codes_id[fec_scheme] if isinstance(fec_scheme, str) else int(fec_scheme)
+        res = _TxResult()
+        st = _lib.current_stream_ptr()
+        h = self._device_handle()
+        _lib.check(_lib.lib().dtl_tx_process(h, user.data_ptr(), user.numel(), int(constellation), fec_idx,
+                                             int(first_frame_no), int(first_tb_no), int(gap), int(bool(want_syms)), st,
+                                             C.byref(res)))
+        nf = int(res.n_frames)
+        hdrs = np.empty(nf, dtype=_TXF_DTYPE)
+        if nf:
+            C.memmove(hdrs.ctypes.data, res.frames, nf * hdrs.itemsize)
+        dev = user.device
+
+        def grab(ptr, shape, dtype):
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            if t.numel() and ptr:
+                _lib.check(_lib.lib().dtl_copy_device(t.data_ptr(), ptr, t.numel() * t.element_size(), st))
+            return t
+        iq = grab(res.d_iq, (nf, int(res.frame_samples) + int(gap)), torch.complex64)
+        syms = grab(res.d_syms, (nf, int(res.frame_capacity)), torch.uint8) if want_syms else None
+        return iq, hdrs, syms
+
+
+class TxFrameInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("payload_len", "frame_no", "cnst", "fb_cnst", "tb_no", "fec_fb", "tb_offset",
+                                         "fec", "tb_payload", "pad")]
+
+
+class _TxResult(C.Structure):
+    _fields_ = [("n_frames", C.c_int64), ("n_samples", C.c_int64), ("n_tbs", C.c_int64),
+                ("frames", C.POINTER(TxFrameInfo)), ("d_iq", C.c_void_p), ("d_syms", C.c_void_p),
+                ("d_hdr_bits", C.c_void_p), ("frame_capacity", C.c_int32), ("hdr_bits", C.c_int32),
+                ("frame_samples", C.c_int32), ("pad", C.c_int32)]
+
+
+_TXF_DTYPE = np.dtype([(n, "<i4") for n, _ in TxFrameInfo._fields_])
 
 
 class ofdm_adaptive_tx:

@@ -193,6 +193,39 @@ void dtl_rx_reset(dtl_rx* h);
 /* samples consumed since the last reset */
 int64_t dtl_rx_stream_position(const dtl_rx* h);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Batched transmitter (the frame generator).  Replaces the TX hier block of
+ * python/dtl/ofdm_transmitter.py:63-189 for one PDU and a constant MCS: ofdm_adaptive_fec_frame_bvb
+ * (lib/dtl/ofdm_adaptive_fec_frame_bvb_impl.cc:284-565) + tb_encoder (lib/dtl/tb_encoder.cc:32-74) + ldpc_enc
+ * (lib/dtl/ldpc_enc.cc:58-68), or ofdm_adaptive_frame_bb (lib/dtl/ofdm_adaptive_frame_bb_impl.cc:131-163);
+ * header formatter (lib/dtl/ofdm_adaptive_packet_header.cc:141-199); chunks_to_symbols, carrier allocator,
+ * inverse FFT, cyclic prefix.  Uses the carrier / pilot / sync-word / FEC fields of dtl_rx_cfg.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct dtl_tx dtl_tx;
+
+typedef struct dtl_tx_frame_info {   /* the packet-header fields of one transmitted frame */
+    int32_t payload_len, frame_no, cnst, fb_cnst, tb_no, fec_fb, tb_offset, fec, tb_payload, pad;
+} dtl_tx_frame_info;
+
+/* Pointers are owned by the handle and stay valid until the next dtl_tx_process / destroy. */
+typedef struct dtl_tx_result {
+    int64_t n_frames, n_samples, n_tbs;
+    const dtl_tx_frame_info* frames;
+    const float* d_iq;            /* n_samples complex64 on the device: frames back to back (+ gap zeros each) */
+    const uint8_t* d_syms;        /* optional: n_frames x frame_capacity constellation indices */
+    const uint8_t* d_hdr_bits;    /* n_frames x hdr_bits header bits (1 bit per byte) */
+    int32_t frame_capacity, hdr_bits, frame_samples, pad;
+} dtl_tx_result;
+
+int dtl_tx_create(const dtl_rx_cfg* cfg, dtl_tx** out);
+void dtl_tx_destroy(dtl_tx* h);
+/* d_user: n_user bytes on the device; constellation 1..4; fec = FEC id (0 / ignored without FEC);
+ * first_frame_no / first_tb_no continue the numbering of a previous call (mixed-MCS streams);
+ * gap = zero samples appended to every frame; want_syms != 0 also returns the symbol indices. */
+int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t constellation, int32_t fec,
+                   int32_t first_frame_no, int32_t first_tb_no, int32_t gap, int32_t want_syms, void* stream,
+                   dtl_tx_result* out);
+
 /* device-to-device copy on `stream` (lets a host binding snapshot result buffers it does not own) */
 int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);
 
