@@ -47,29 +47,35 @@ def build_config(dtl, w):
 
 
 def synth_stream(dtl, cfg, w, n_frames, device, seed):
-    """Synthetic AWGN IQ frames of the named FFT/codeword sizes: a tile of frames from the product's
-    own transmitter (gr_dtl_amd.ofdm_transmitter), repeated on the GPU, plus independent complex AWGN."""
+    """Synthetic AWGN IQ frames of the named FFT/codeword sizes: independent random payload for every frame,
+    framed / LDPC-encoded / OFDM-modulated on the GPU by the product's own transmitter
+    (gr_dtl_amd.ofdm_transmitter.work_device), 100 leading zeros, one frame of trailing zeros, plus
+    independent complex AWGN.  -> (iq, frames, user bytes sent, user tensor)"""
     import torch
     from gr_dtl_amd.ofdm_transmitter import ofdm_transmitter
     tx = ofdm_transmitter(cfg)
     bps = int(w["cnst"])
-    tile_frames = min(256, n_frames)
     frame_bytes = tx.frame_capacity * bps // 8
-    rng = np.random.default_rng(0xD71 + seed)
-    user = rng.integers(0, 256, int(tile_frames * frame_bytes * 0.49), dtype=np.uint8)  # rate ~1/2 code
-    iq, hdrs = tx.work(user, w["cnst"], "fec_1")
-    tile = torch.from_numpy(iq.reshape(-1)).to(device)
-    reps = max(1, round(n_frames / len(hdrs)))
-    lead = torch.zeros(100, dtype=torch.complex64, device=device)         # qa_ofdm_adaptive_txrx.py:82-83
-    tail = torch.zeros(tx.frame_samples, dtype=torch.complex64, device=device)
-    x = torch.cat([lead, tile.repeat(reps), tail])
-    nv = w["fft_len"] * ES[w["cnst"]] / 10 ** (w["esn0_db"] / 10)
     g = torch.Generator(device=device)
+    g.manual_seed(0xD71 + seed)
+    # user bytes that fill n_frames frames: whole transport blocks of the LDPC(300,152) code (tb_encoder split)
+    n_code, k_code = 300, 152
+    ncws = 1 + frame_bytes * 8 // n_code if frame_bytes * 8 > n_code else 1
+    tb_payload = ncws * k_code // 8 - 4
+    tb_coded_bytes = (ncws * (n_code - k_code) + (tb_payload + 4) * 8) / 8.0
+    n_user = int(n_frames * frame_bytes / tb_coded_bytes) * tb_payload
+    user = torch.randint(0, 256, (n_user,), dtype=torch.uint8, device=device, generator=g)
+    iq, hdrs, _ = tx.work_device(user, w["cnst"], "fec_1")
+    lead = torch.zeros(100, dtype=torch.complex64, device=device)             # qa_ofdm_adaptive_txrx.py:82-83
+    tail = torch.zeros(tx.frame_samples, dtype=torch.complex64, device=device)
+    x = torch.cat([lead, iq.reshape(-1), tail])
+    del iq
+    nv = w["fft_len"] * ES[w["cnst"]] / 10 ** (w["esn0_db"] / 10)
     g.manual_seed(1234 + seed)
     noise = torch.randn((x.numel(), 2), generator=g, device=device, dtype=torch.float32) * float(np.sqrt(nv / 2))
-    x = x + torch.view_as_complex(noise)
+    x += torch.view_as_complex(noise)
     del noise
-    return x, reps * len(hdrs), len(user) * reps
+    return x, len(hdrs), n_user, user
 
 
 def cpu_baseline(cfg, w, x_host, n_frames_sample):
@@ -127,7 +133,7 @@ def main():
     n_frames_req = args.frames or w["frames"]
     cfg = build_config(dtl, w)
     rx = dtl.ofdm_receiver(cfg)
-    x, n_frames, n_user = synth_stream(dtl, cfg, w, n_frames_req, device, seed=rank)
+    x, n_frames, n_user, _ = synth_stream(dtl, cfg, w, n_frames_req, device, seed=rank)
     n_samples = x.numel()
     torch.cuda.synchronize()
 
@@ -179,7 +185,7 @@ def main():
             "metric": "Msamples/s thru OFDM RX (sync>FFT>eq>demap>LDPC)", "value": round(value, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (sync/FFT/eq/demap) + f64 (LDPC BP)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (sync/FFT/eq/demap) + f64 (LDPC BP)", "data": "synthetic (unique random payload per frame, product GPU TX + AWGN)",
             "config": {"workload": w["desc"], "fft_len": w["fft_len"], "frames_per_gpu": n_frames,
                        "samples_per_gpu": n_samples, "constellation": int(w["cnst"]), "esn0_db": w["esn0_db"],
                        "sync_threshold": w["sync_threshold"], "ldpc": "n=300 k=152, <=15 it, f64 LR-domain SPA",

@@ -15,7 +15,7 @@ w = bench.WORKLOADS["c3"]
 cfg = bench.build_config(dtl, w)
 rx = dtl.ofdm_receiver(cfg)
 dev = torch.device("cuda", 0)
-x, n_frames, _ = bench.synth_stream(dtl, cfg, w, int(os.environ.get("FRAMES", "65536")), dev, 0)
+x, n_frames, _, _ = bench.synth_stream(dtl, cfg, w, int(os.environ.get("FRAMES", "65536")), dev, 0)
 torch.cuda.synchronize()
 for _ in range(2):
     rx.work(x, copy_outputs=False)
