@@ -108,12 +108,13 @@ __device__ __forceinline__ void load_and_fft2(const RxTables& t, const cf32* __r
     cf32* buf = upper ? bufB : bufA;
     const int bt = upper ? tid - hN : tid;
     const bool active = !upper || symB >= 0;
-    for (int len = 2; len <= N; len <<= 1) {
-        const int half = len >> 1;
+    const int logN = __ffs(N) - 1;
+    for (int st = 0; st < logN; st++) { // stage st: butterflies of span len = 2^(st+1); shifts, not divisions
+        const int half = 1 << st;
         if (active) {
-            const int grp = bt / half, k = bt - grp * half;
-            const int a = grp * len + k, b = a + half;
-            const cf32 w = tw[k * (N / len)];
+            const int grp = bt >> st, k = bt & (half - 1);
+            const int a = (grp << (st + 1)) + k, b = a + half;
+            const cf32 w = tw[k << (logN - st - 1)];
             const cf32 u = buf[a];
             const cf32 vv = cmul(buf[b], w);
             buf[a] = cadd(u, vv);

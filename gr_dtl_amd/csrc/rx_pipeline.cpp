@@ -369,6 +369,7 @@ int64_t Receiver::stream_position() const { return ss_->next_abs; }
 Receiver::~Receiver()
 {
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& e : chunk_ev_) if (e) (void)hipEventDestroy(e);
 }
 
 int Receiver::init()
@@ -747,8 +748,23 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     const int n_cand = int(cands.size());
     stage_ms[1] = now_ms() - t0; t0 = now_ms();
 
-    // ---- phase A: header kernel
+    // ---- phases A and B, pipelined over chunks of candidates: the header kernel of every chunk is queued
+    // at once; while the GPU works through them the host takes chunk after chunk of header records
+    // (header_payload_demux walk + header_parser state, both sequential) and queues that chunk's payload
+    // kernel behind them.  Only the walk of the last chunk is not hidden behind GPU work.
     std::vector<HeaderRec> recs(n_cand);
+    std::vector<FrameDesc> fdesc;
+    std::vector<uint32_t> llr_off;
+    fdesc.reserve(n_cand);
+    llr_off.reserve(n_cand);
+    frames.reserve(n_cand);
+    const int n_chunks = n_cand >= 8192 ? 4 : 1;
+    const int max_bps = 4;
+    const int nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
+    cf32 *eh = nullptr, *es = nullptr, *ss_out = nullptr;
+    uint8_t* nofec_bytes = nullptr;
+    int32_t* nofec_inf = nullptr;
+    uint64_t llr_total = uint64_t(ss.llr_carry_len);
     if (n_cand) {
         std::vector<CfoSegment> segs_rel(ss.segs);
         for (auto& sg : segs_rel) sg.start -= A;
@@ -758,103 +774,119 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         DTL_TRY(d_taps.ensure(size_t(n_cand) * N * sizeof(cf32)));
         uint8_t* hb = nullptr;
         if (flags & RX_WANT_HDR_BITS) { DTL_TRY(d_hdr_bits.ensure(size_t(n_cand) * tab_.hdr_bits)); hb = d_hdr_bits.as<uint8_t>(); }
-        DTL_TRY(upload_vec(h_cands_, d_cands_, cands, st));
-        DTL_TRY(upload_vec(h_segs_, d_segs_, segs_rel, st));
-        DTL_TRY(launch_header(tab_, iq, W, d_cands_.as<Candidate>(), n_cand, d_segs_.as<CfoSegment>(), n_segs,
-                              d_recs_.as<HeaderRec>(), d_taps.as<cf32>(), hb, st));
-        DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.p, d_recs_.p, size_t(n_cand) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
-        DTL_HIP_CHECK(hipStreamSynchronize(st));
-        std::memcpy(recs.data(), h_recs_.p, size_t(n_cand) * sizeof(HeaderRec));
-    }
-    stage_ms[2] = now_ms() - t0; t0 = now_ms();
-
-    // ---- header_payload_demux walk + header_parser state
-    std::vector<FrameDesc> fdesc;
-    std::vector<uint32_t> llr_off;
-    fdesc.reserve(n_cand);
-    frames.reserve(n_cand);
-    int n_walked = 0; // candidates the demux has dealt with
-    for (int ci = 0; ci < n_cand; ci++) {
-        const int64_t trig = cand_abs[ci];
-        n_walked = ci + 1;
-        if (trig < ss.demux_pos) continue; // consumed by a previous frame
-        const HeaderRec& r = recs[ci];
-        FrameInfo fi{};
-        fi.trigger = trig; fi.header_ok = r.crc_ok; fi.carr_offset = r.carr_offset; fi.payload_index = -1; fi.cand = ci;
-        fi.llr_offset = -1;
-        if (!r.crc_ok) { frames.push_back(fi); ss.demux_pos = trig + 1; continue; }
-        if (trig + int64_t(hdr_syms + L) * P > E) break; // only at the end of a stream
-        if (r.cnst && r.cnst <= 4) ss.state_cnst = r.cnst; // :269-273
-        const int bps = bits_per_symbol(ss.state_cnst);
-        int n_syms = r.payload_len * 8 / bps;
-        if (r.payload_len * 8 % bps) n_syms++;
-        fi.payload_len = r.payload_len; fi.frame_no = r.frame_no; fi.cnst = ss.state_cnst; fi.fb_cnst = r.fb_cnst;
-        fi.tb_no = r.tb_no; fi.fec_fb = r.fec_fb; fi.tb_offset = r.tb_offset; fi.fec = r.fec; fi.tb_payload = r.tb_payload;
-        fi.n_payload_syms = n_syms;
-        fi.payload_index = int(fdesc.size());
-        FrameDesc d{};
-        d.trigger = trig - A; d.seg = cands[ci].seg; d.cand = ci; d.cnst = ss.state_cnst; d.carr_offset = r.carr_offset;
-        // ofdm_serializer_vcc truncation to packet_length; payload == 0 frames are dropped (:218,254)
-        d.n_syms = r.payload_len ? std::min(n_syms, capacity_) : 0;
-        fdesc.push_back(d);
-        frames.push_back(fi);
-        ss.demux_pos = trig + int64_t(hdr_syms + L) * P;
-    }
-    ss.pending_fixed.erase(ss.pending_fixed.begin(), ss.pending_fixed.begin() + n_walked);
-    const int n_frames = int(fdesc.size());
-    n_payload_frames = n_frames;
-
-    // ---- soft-bit stream layout (after the soft bits carried for an unfinished transport block)
-    // + transport-block gather tables (tb_decoder::process_frame)
-    llr_off.assign(n_frames, 0);
-    uint64_t llr_total = uint64_t(ss.llr_carry_len);
-    for (int f = 0; f < n_frames; f++) {
-        llr_off[f] = uint32_t(llr_total);
-        llr_total += uint64_t(fdesc[f].n_syms) * bits_per_symbol(fdesc[f].cnst);
-    }
-    if (llr_total + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
-    n_llr = int64_t(llr_total);
-    {
-        size_t fidx = 0;
-        for (auto& fi : frames) if (fi.payload_index >= 0) { fi.llr_offset = llr_off[fidx]; fidx++; }
-    }
-    // ---- phase B starts now: the payload kernel only needs the frame descriptors and the soft-bit
-    // offsets; the transport-block bookkeeping below runs on the host while it executes.
-    std::vector<FrameStat> stats(n_frames);
-    std::vector<int32_t> nofec_info(size_t(n_frames) * 2, 0);
-    uint32_t total_bytes = 0;
-    const int nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
-    if (n_frames || ss.llr_carry_len) {
-        DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
+        // per-frame buffers of phase B, sized for "every candidate becomes a frame at the densest constellation"
+        const uint64_t llr_bound = llr_total + uint64_t(n_cand) * capacity_ * max_bps;
+        DTL_TRY(d_llr.ensure((size_t(std::min<uint64_t>(llr_bound, 0xFFFFFFF0ull)) + 4096) * 4));
         if (ss.llr_carry_len)
             DTL_HIP_CHECK(hipMemcpyAsync(d_llr.p, d_llr_carry_.p, size_t(ss.llr_carry_len) * 4, hipMemcpyDeviceToDevice, st));
-    }
-    if (n_frames) {
-        DTL_TRY(d_stats_.ensure(size_t(n_frames) * sizeof(FrameStat)));
-        cf32 *eh = nullptr, *es = nullptr, *ss_out = nullptr;
-        if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_frames) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
-        if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_frames) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
+        DTL_TRY(d_stats_.ensure(size_t(n_cand) * sizeof(FrameStat)));
+        DTL_TRY(d_frames_.ensure(size_t(n_cand) * sizeof(FrameDesc)));
+        DTL_TRY(h_frames_.ensure(size_t(n_cand) * sizeof(FrameDesc)));
+        DTL_TRY(d_llr_off_.ensure(size_t(n_cand) * 4));
+        DTL_TRY(h_llr_off_.ensure(size_t(n_cand) * 4));
+        if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_cand) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
+        if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_cand) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
         if (flags & RX_WANT_SOFT_SYMS) {
-            DTL_TRY(d_soft_syms.ensure(size_t(n_frames) * capacity_ * sizeof(cf32)));
-            DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_frames) * capacity_ * sizeof(cf32), st));
+            DTL_TRY(d_soft_syms.ensure(size_t(n_cand) * capacity_ * sizeof(cf32)));
+            DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_cand) * capacity_ * sizeof(cf32), st));
             ss_out = d_soft_syms.as<cf32>();
         }
-        uint8_t* nofec_bytes = nullptr;
-        int32_t* nofec_inf = nullptr;
         if (!cfg.has_fec) {
-            DTL_TRY(d_staging_.ensure(size_t(n_frames) * nofec_stride));
-            DTL_TRY(d_nofec_info_.ensure(size_t(n_frames) * 8));
-            DTL_HIP_CHECK(hipMemsetAsync(d_nofec_info_.p, 0, size_t(n_frames) * 8, st));
+            DTL_TRY(d_staging_.ensure(size_t(n_cand) * nofec_stride));
+            DTL_TRY(d_nofec_info_.ensure(size_t(n_cand) * 8));
+            DTL_HIP_CHECK(hipMemsetAsync(d_nofec_info_.p, 0, size_t(n_cand) * 8, st));
             nofec_bytes = d_staging_.as<uint8_t>();
             nofec_inf = d_nofec_info_.as<int32_t>();
         }
-        DTL_TRY(upload_vec(h_frames_, d_frames_, fdesc, st));
-        DTL_TRY(upload_vec(h_llr_off_, d_llr_off_, llr_off, st));
-        if (ev_[0]) DTL_HIP_CHECK(hipEventRecord(ev_[0], st));
-        DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>(), n_frames, d_segs_.as<CfoSegment>(), n_segs,
-                               d_taps.as<cf32>(), d_stats_.as<FrameStat>(), d_llr_off_.as<uint32_t>(),
-                               d_llr.as<float>(), eh, es, ss_out, nofec_bytes, nofec_inf, nofec_stride, st));
-        if (ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
+        DTL_TRY(upload_vec(h_cands_, d_cands_, cands, st));
+        DTL_TRY(upload_vec(h_segs_, d_segs_, segs_rel, st));
+        while (int(chunk_ev_.size()) < n_chunks) {
+            hipEvent_t e = nullptr;
+            DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            chunk_ev_.push_back(e);
+        }
+        for (int c = 0; c < n_chunks; c++) {
+            const int c0 = int(int64_t(n_cand) * c / n_chunks), c1 = int(int64_t(n_cand) * (c + 1) / n_chunks);
+            if (c1 <= c0) continue;
+            DTL_TRY(launch_header(tab_, iq, W, d_cands_.as<Candidate>() + c0, c1 - c0, d_segs_.as<CfoSegment>(), n_segs,
+                                  d_recs_.as<HeaderRec>() + c0, d_taps.as<cf32>() + size_t(c0) * N,
+                                  hb ? hb + size_t(c0) * tab_.hdr_bits : nullptr, st));
+            DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + c0, d_recs_.as<HeaderRec>() + c0,
+                                         size_t(c1 - c0) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
+            DTL_HIP_CHECK(hipEventRecord(chunk_ev_[c], st));
+        }
+    }
+    int n_walked = 0; // candidates the demux has dealt with
+    bool stop = false, payload_started = false;
+    for (int c = 0; c < n_chunks && n_cand; c++) {
+        const int c0 = int(int64_t(n_cand) * c / n_chunks), c1 = int(int64_t(n_cand) * (c + 1) / n_chunks);
+        if (c1 <= c0) continue;
+        DTL_HIP_CHECK(hipEventSynchronize(chunk_ev_[c]));
+        if (c == 0) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }
+        std::memcpy(recs.data() + c0, h_recs_.as<HeaderRec>() + c0, size_t(c1 - c0) * sizeof(HeaderRec));
+        const int f0 = int(fdesc.size());
+        for (int ci = c0; ci < c1 && !stop; ci++) {
+            const int64_t trig = cand_abs[ci];
+            n_walked = ci + 1;
+            if (trig < ss.demux_pos) continue; // consumed by a previous frame
+            const HeaderRec& r = recs[ci];
+            FrameInfo fi{};
+            fi.trigger = trig; fi.header_ok = r.crc_ok; fi.carr_offset = r.carr_offset; fi.payload_index = -1; fi.cand = ci;
+            fi.llr_offset = -1;
+            if (!r.crc_ok) { frames.push_back(fi); ss.demux_pos = trig + 1; continue; }
+            if (trig + int64_t(hdr_syms + L) * P > E) { stop = true; break; } // only at the end of a stream
+            if (r.cnst && r.cnst <= 4) ss.state_cnst = r.cnst; // :269-273
+            const int bps = bits_per_symbol(ss.state_cnst);
+            int n_syms = r.payload_len * 8 / bps;
+            if (r.payload_len * 8 % bps) n_syms++;
+            fi.payload_len = r.payload_len; fi.frame_no = r.frame_no; fi.cnst = ss.state_cnst; fi.fb_cnst = r.fb_cnst;
+            fi.tb_no = r.tb_no; fi.fec_fb = r.fec_fb; fi.tb_offset = r.tb_offset; fi.fec = r.fec; fi.tb_payload = r.tb_payload;
+            fi.n_payload_syms = n_syms;
+            fi.payload_index = int(fdesc.size());
+            FrameDesc d{};
+            d.trigger = trig - A; d.seg = cands[ci].seg; d.cand = ci; d.cnst = ss.state_cnst; d.carr_offset = r.carr_offset;
+            // ofdm_serializer_vcc truncation to packet_length; payload == 0 frames are dropped (:218,254)
+            d.n_syms = r.payload_len ? std::min(n_syms, capacity_) : 0;
+            // soft-bit stream layout: frame after frame, behind the soft bits carried for an unfinished TB
+            fi.llr_offset = int64_t(llr_total);
+            llr_off.push_back(uint32_t(llr_total));
+            llr_total += uint64_t(d.n_syms) * bps;
+            if (llr_total + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
+            fdesc.push_back(d);
+            frames.push_back(fi);
+            ss.demux_pos = trig + int64_t(hdr_syms + L) * P;
+        }
+        // ---- phase B for the frames of this chunk (tb bookkeeping runs on the host while it executes)
+        const int f1 = int(fdesc.size());
+        if (f1 > f0) {
+            std::memcpy(h_frames_.as<FrameDesc>() + f0, fdesc.data() + f0, size_t(f1 - f0) * sizeof(FrameDesc));
+            std::memcpy(h_llr_off_.as<uint32_t>() + f0, llr_off.data() + f0, size_t(f1 - f0) * 4);
+            DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.as<FrameDesc>() + f0, h_frames_.as<FrameDesc>() + f0,
+                                         size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+            DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.as<uint32_t>() + f0, h_llr_off_.as<uint32_t>() + f0, size_t(f1 - f0) * 4,
+                                         hipMemcpyHostToDevice, st));
+            if (!payload_started && ev_[0]) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
+            DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
+                                   d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0, d_llr_off_.as<uint32_t>() + f0,
+                                   d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
+                                   ss_out ? ss_out + size_t(f0) * capacity_ : nullptr,
+                                   nofec_bytes ? nofec_bytes + size_t(f0) * nofec_stride : nullptr,
+                                   nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st));
+        }
+        if (stop) break;
+    }
+    if (!n_cand) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }
+    if (payload_started && ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
+    ss.pending_fixed.erase(ss.pending_fixed.begin(), ss.pending_fixed.begin() + n_walked);
+    const int n_frames = int(fdesc.size());
+    n_payload_frames = n_frames;
+    n_llr = int64_t(llr_total);
+    std::vector<FrameStat> stats(n_frames);
+    std::vector<int32_t> nofec_info(size_t(n_frames) * 2, 0);
+    uint32_t total_bytes = 0;
+    if (!n_cand && ss.llr_carry_len) { // nothing new, but a transport block is still waiting for its frames
+        DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
+        DTL_HIP_CHECK(hipMemcpyAsync(d_llr.p, d_llr_carry_.p, size_t(ss.llr_carry_len) * 4, hipMemcpyDeviceToDevice, st));
     }
     TbAssembler& asmb = ss.asmb;
     asmb.done.clear();

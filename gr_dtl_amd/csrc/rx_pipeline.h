@@ -149,6 +149,7 @@ private:
     HostBuf h_small_, h_edges_, h_trig_, h_angle_, h_cands_, h_segs_, h_recs_, h_frames_, h_llr_off_, h_gather_,
         h_tbdesc_, h_stats_, h_tbres_, h_nofec_;
     DevBuf d_work_, d_carry_, d_llr_carry_;
+    std::vector<hipEvent_t> chunk_ev_; // one per candidate chunk of the phase A/B pipeline
 };
 
 } // namespace dtl

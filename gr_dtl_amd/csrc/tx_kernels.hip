@@ -155,7 +155,7 @@ __global__ void tx_frame_kernel(TxTables t, const TxFrame* __restrict__ frames, 
         const int i = s - 2, len = t.occ_len[i % t.n_occ_sets];
         if (i < h) hdr_pos += len; else pay_pos += len;
     };
-    const int hN = N / 2;
+    const int hN = N / 2, logN = __ffs(N) - 1;
     for (int s0 = 0; s0 < n_sym; s0 += 2) {
         const bool two = s0 + 1 < n_sym;
         bufA[br] = freq_value(s0, hdr_pos, pay_pos);
@@ -166,12 +166,12 @@ __global__ void tx_frame_kernel(TxTables t, const TxFrame* __restrict__ frames, 
         cf32* buf = upper ? bufB : bufA;
         const int bt = upper ? tid - hN : tid;
         const bool active = !upper || two;
-        for (int len = 2; len <= N; len <<= 1) {
-            const int half = len >> 1;
+        for (int st = 0; st < logN; st++) { // butterflies of span 2^(st+1); shifts, not divisions
+            const int half = 1 << st;
             if (active) {
-                const int grp = bt / half, k = bt - grp * half;
-                const int a = grp * len + k, b = a + half;
-                const cf32 w = tw[k * (N / len)];
+                const int grp = bt >> st, k = bt & (half - 1);
+                const int a = (grp << (st + 1)) + k, b = a + half;
+                const cf32 w = tw[k << (logN - st - 1)];
                 const cf32 u = buf[a];
                 const cf32 vv = cmul(buf[b], w);
                 buf[a] = { u.re + vv.re, u.im + vv.im };
