@@ -637,41 +637,86 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     }
     lap("work buffer");
 
-    // ---- K1: timing metric -> threshold crossings -> plateau detector (host)
-    std::vector<unsigned long long> edges;
-    if (n > 0) {
-        const unsigned max_edges = unsigned(std::min<int64_t>(std::max<int64_t>(n / 8, 1024), 1 << 26));
-        DTL_TRY(d_edges_.ensure(size_t(max_edges) * 8));
-        DTL_TRY(d_counter_.ensure(16));
-        DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 16, st));
-        float* metric = nullptr;
-        if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
-        DTL_TRY(launch_sync_edges(iq, W, B - A, N, cfg.sync_threshold, d_edges_.as<unsigned long long>(),
-                                  d_counter_.as<unsigned int>(), max_edges, metric, st));
-        lap("launch sync");
-        DTL_TRY(h_small_.ensure(64));
-        DTL_HIP_CHECK(hipMemcpyAsync(h_small_.p, d_counter_.p, 4, hipMemcpyDeviceToHost, st));
-        DTL_HIP_CHECK(hipStreamSynchronize(st));
-        lap("sync wait");
-        const unsigned n_edges = *h_small_.as<unsigned>();
-        if (n_edges > max_edges) { set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
-        edges.resize(n_edges);
-        if (n_edges) {
-            DTL_TRY(h_edges_.ensure(size_t(n_edges) * 8));
-            DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.p, d_edges_.p, size_t(n_edges) * 8, hipMemcpyDeviceToHost, st));
-            DTL_HIP_CHECK(hipStreamSynchronize(st));
-            std::memcpy(edges.data(), h_edges_.p, size_t(n_edges) * 8);
-        }
-        lap("edges d2h");
-        dbg_n_edges = n_edges;
-    }
-    const double t_e = now_ms();
-    sort_edges(edges);
-    if (A) for (auto& e : edges) e += static_cast<unsigned long long>(A) << 1; // buffer-relative -> absolute
+    // ---- K1: timing metric -> threshold crossings -> plateau detector (host), pipelined over up to four
+    // sample ranges: the crossings of one range are sorted and run through the (incremental) plateau
+    // detector while the sync kernel works on the next range.
     int64_t produced = E;
-    raw_triggers = plateau_stream(ss.edge_carry, edges, ss.plateau_i, E, cp, final, &produced);
+    double plateau_ms = 0.0;
+    unsigned n_edges_total = 0;
+    {
+        const int64_t mb0 = B - A;
+        const int n_sc = n >= (int64_t(1) << 26) ? 4 : 1;
+        struct Range { int64_t mb, me; unsigned max_edges, guess; size_t off; };
+        std::vector<Range> rg;
+        size_t edge_slots = 0;
+        for (int c = 0; c < n_sc && n > 0; c++) {
+            int64_t mb = mb0 + n * c / n_sc, me = mb0 + n * (c + 1) / n_sc;
+            if (c) mb &= ~int64_t(kSyncTileSamples - 1);               // ranges meet on tile boundaries
+            if (c + 1 < n_sc) me &= ~int64_t(kSyncTileSamples - 1);
+            if (me <= mb) continue;
+            Range r{ mb, me, unsigned(std::min<int64_t>(std::max<int64_t>((me - mb) / 8, 1024), 1 << 26)), 0, edge_slots };
+            // crossings expected in a stream of frames: two per preamble; copied back together with the counter
+            r.guess = unsigned(std::min<int64_t>(r.max_edges, 4 * ((me - mb) / frame_samples() + 1) + 1024));
+            edge_slots += r.max_edges;
+            rg.push_back(r);
+        }
+        if (!rg.empty()) {
+            DTL_TRY(d_edges_.ensure(edge_slots * 8));
+            DTL_TRY(d_counter_.ensure(16));
+            DTL_TRY(h_small_.ensure(64));
+            size_t guess_total = 0;
+            for (auto& r : rg) guess_total += r.guess;
+            DTL_TRY(h_edges_.ensure(guess_total * 8));
+            DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 16, st));
+            float* metric = nullptr;
+            if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
+            while (chunk_ev_.size() < rg.size()) {
+                hipEvent_t e = nullptr;
+                DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                chunk_ev_.push_back(e);
+            }
+            size_t hoff = 0;
+            for (size_t c = 0; c < rg.size(); c++) {
+                const Range& r = rg[c];
+                DTL_TRY(launch_sync_edges(iq, r.me, r.mb, N, cfg.sync_threshold, d_edges_.as<unsigned long long>() + r.off,
+                                          d_counter_.as<unsigned int>() + c, r.max_edges, metric ? metric + (r.mb - mb0) : nullptr, st));
+                DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<unsigned>() + c, d_counter_.as<unsigned int>() + c, 4, hipMemcpyDeviceToHost, st));
+                DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.as<unsigned long long>() + hoff, d_edges_.as<unsigned long long>() + r.off,
+                                             size_t(r.guess) * 8, hipMemcpyDeviceToHost, st));
+                DTL_HIP_CHECK(hipEventRecord(chunk_ev_[c], st));
+                hoff += r.guess;
+            }
+            lap("launch sync");
+            hoff = 0;
+            for (size_t c = 0; c < rg.size(); c++) {
+                const Range& r = rg[c];
+                DTL_HIP_CHECK(hipEventSynchronize(chunk_ev_[c]));
+                const unsigned n_edges = h_small_.as<unsigned>()[c];
+                if (n_edges > r.max_edges) { set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
+                std::vector<unsigned long long> edges(n_edges);
+                std::memcpy(edges.data(), h_edges_.as<unsigned long long>() + hoff, size_t(std::min(n_edges, r.guess)) * 8);
+                if (n_edges > r.guess) { // more crossings than a frame stream produces: fetch the rest (all ranges are done by then or soon)
+                    DTL_HIP_CHECK(hipMemcpy(edges.data() + r.guess, d_edges_.as<unsigned long long>() + r.off + r.guess,
+                                            size_t(n_edges - r.guess) * 8, hipMemcpyDeviceToHost));
+                }
+                hoff += r.guess;
+                const double t_e = now_ms();
+                sort_edges(edges);
+                if (A) for (auto& e : edges) e += static_cast<unsigned long long>(A) << 1; // buffer-relative -> absolute
+                const bool last = c + 1 == rg.size();
+                std::vector<int64_t> trig = plateau_stream(ss.edge_carry, edges, ss.plateau_i, A + r.me, cp, final && last, &produced);
+                raw_triggers.insert(raw_triggers.end(), trig.begin(), trig.end());
+                plateau_ms += now_ms() - t_e;
+                n_edges_total += n_edges;
+            }
+        } else {
+            // no new samples (a final flush): close what is open
+            raw_triggers = plateau_stream(ss.edge_carry, {}, ss.plateau_i, E, cp, final, &produced);
+        }
+    }
+    dbg_n_edges = n_edges_total;
     stage_ms[0] = now_ms() - t0; t0 = now_ms();
-    dbg_plateau_ms = t0 - t_e;
+    dbg_plateau_ms = plateau_ms;
 
     // ---- K1b: arg(P) at the raw triggers; oscillator segments (sample_and_hold + frequency_modulator_fc)
     const int n_raw = int(raw_triggers.size());
