@@ -729,29 +729,15 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         DTL_TRY(upload_vec(h_trig_, d_trig_, rel, st));
         DTL_TRY(launch_trigger_angle(iq, W, N, d_trig_.as<int64_t>(), n_raw, d_angle_.as<float>(), st));
         DTL_HIP_CHECK(hipMemcpyAsync(h_angle_.p, d_angle_.p, size_t(n_raw) * 4, hipMemcpyDeviceToHost, st));
-        DTL_HIP_CHECK(hipStreamSynchronize(st));
-        std::memcpy(trigger_angles.data(), h_angle_.p, size_t(n_raw) * 4);
+        // the angles are collected further down: frame_detect_bb and the candidate list only need the trigger
+        // POSITIONS and run on the host while the kernel and the copy are in flight
     }
-    {
-        // the phase a segment starts with is the previous segment's phase advanced to the new trigger
-        // (before the first trigger the held angle is 0 and the phase stays 0)
-        const float sens = float(-2.0 / N);
-        ss.segs.reserve(ss.segs.size() + n_raw);
-        for (int j = 0; j < n_raw; j++) {
-            CfoSegment sg{};
-            sg.start = raw_triggers[j];
-            sg.angle = trigger_angles[j];
-            sg.phase0 = 0.0;
-            if (!ss.segs.empty()) {
-                const CfoSegment& pv = ss.segs.back();
-                double phase = pv.phase0 + double(sens * pv.angle) * double(sg.start - pv.start);
-                phase = std::fmod(phase + M_PI, 2.0 * M_PI);
-                if (phase < 0) phase += 2.0 * M_PI;
-                phase -= M_PI;
-                sg.phase0 = phase;
-            }
-            ss.segs.push_back(sg);
-        }
+    const size_t first_new_seg = ss.segs.size();
+    ss.segs.reserve(ss.segs.size() + n_raw);
+    for (int j = 0; j < n_raw; j++) {
+        CfoSegment sg{};
+        sg.start = raw_triggers[j];
+        ss.segs.push_back(sg);
     }
     const int n_segs = int(ss.segs.size());
     // ---- frame_detect_bb (optional): one work() buffer = the trigger stream produced by this call
@@ -791,6 +777,26 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         }
     }
     const int n_cand = int(cands.size());
+    if (n_raw) {
+        DTL_HIP_CHECK(hipStreamSynchronize(st));
+        std::memcpy(trigger_angles.data(), h_angle_.p, size_t(n_raw) * 4);
+        // the phase a segment starts with is the previous segment's phase advanced to the new trigger
+        // (before the first trigger the held angle is 0 and the phase stays 0)
+        const float sens = float(-2.0 / N);
+        for (int j = 0; j < n_raw; j++) {
+            CfoSegment& sg = ss.segs[first_new_seg + j];
+            sg.angle = trigger_angles[j];
+            sg.phase0 = 0.0;
+            if (first_new_seg + j > 0) {
+                const CfoSegment& pv = ss.segs[first_new_seg + j - 1];
+                double phase = pv.phase0 + double(sens * pv.angle) * double(sg.start - pv.start);
+                phase = std::fmod(phase + M_PI, 2.0 * M_PI);
+                if (phase < 0) phase += 2.0 * M_PI;
+                phase -= M_PI;
+                sg.phase0 = phase;
+            }
+        }
+    }
     stage_ms[1] = now_ms() - t0; t0 = now_ms();
 
     // ---- phases A and B, pipelined over chunks of candidates: the header kernel of every chunk is queued
