@@ -32,7 +32,7 @@ struct LdpcTables {
 // LDS plan of the node-parallel kernel: byte offsets of the shared index tables and of the
 // per-wave slices inside the workgroup's dynamic LDS
 struct NpShared {
-    int row_ptr, edge_var, col_ptr, col_edge, perm, sys_src, wave_base, wave_stride;
+    int chk_var, var_edge, chk_deg, perm, sys_src, wave_base, wave_stride;
 };
 
 class LdpcDecoder {
@@ -54,7 +54,11 @@ private:
     void* blob_ = nullptr;
     // node-parallel kernel (normal path)
     NpShared np_sh_{};
-    const uint16_t* np_col_ptr_ = nullptr;
+    const uint16_t* np_chk_var_ = nullptr;   // m x MAXR: variable per padded message slot (pad: n)
+    const uint16_t* np_var_edge_ = nullptr;  // n x 4: message slots of a variable (pad: the slot kept at 1.0)
+    const uint8_t* np_chk_deg_ = nullptr;    // m: row weights
+    bool np_rows_full_ = false;              // every row has exactly MAXR entries
+    int np_maxr_ = 6;
     const uint16_t* np_perm_ = nullptr;
     unsigned int* np_queue_ = nullptr;  // ticket counter of the codeword queue (one decode() in flight per decoder)
     size_t np_lds_ = 0;

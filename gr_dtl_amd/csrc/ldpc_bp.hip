@@ -163,9 +163,18 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int MAXR, int MAXC, int NV>
+// Index tables of the node-parallel kernel use FIXED strides: check c owns message slots c*MAXR .. c*MAXR+MAXR-1
+// (rows shorter than MAXR are padded), variable v owns four 16-bit slot indices (columns lighter than four
+// entries are padded).  Padding costs no branch: a padded row slot names the dummy variable n, whose channel
+// LR is 0 and whose hard decision is 0 -- its message stays 0, i.e. the factor 2/(1+0)-1 == 1 in the row
+// product -- and a padded column entry names the message slot kept at 1.0 (factor 1 in the column product)
+// while its write is redirected to a trash slot.  Multiplying by exactly 1.0 changes no bit of a product, so
+// the arithmetic is still the reference's, without per-edge degree tests and without row/column pointer reads.
+template <int MAXR, int MAXC, int NV, bool ROWS_FULL>
 __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables t, NpShared sh,
-                                                                     const uint16_t* __restrict__ col_ptr_g,
+                                                                     const uint16_t* __restrict__ chk_var_g,
+                                                                     const uint16_t* __restrict__ var_edge_g,
+                                                                     const uint8_t* __restrict__ chk_deg_g,
                                                                      const uint16_t* __restrict__ perm_g,
                                                                      const float* __restrict__ llr,
                                                                      const CwDesc* __restrict__ desc, int ncw,
@@ -174,26 +183,28 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                                                                      int32_t* __restrict__ out_nit,
                                                                      unsigned int* __restrict__ queue, int chunk)
 {
+    static_assert(MAXC <= 4, "a variable's slot indices are read as one 64-bit word");
     extern __shared__ unsigned char np_smem[];
-    uint16_t* row_ptr = reinterpret_cast<uint16_t*>(np_smem + sh.row_ptr);
-    uint16_t* edge_var = reinterpret_cast<uint16_t*>(np_smem + sh.edge_var);
-    uint16_t* col_ptr = reinterpret_cast<uint16_t*>(np_smem + sh.col_ptr);
-    uint16_t* col_edge = reinterpret_cast<uint16_t*>(np_smem + sh.col_edge);
+    uint16_t* chk_var = reinterpret_cast<uint16_t*>(np_smem + sh.chk_var);    // m * MAXR
+    uint16_t* var_edge = reinterpret_cast<uint16_t*>(np_smem + sh.var_edge);  // n * 4
+    uint8_t* chk_deg = np_smem + sh.chk_deg;                                  // m
     uint16_t* perm = reinterpret_cast<uint16_t*>(np_smem + sh.perm);
     uint16_t* sys_src = reinterpret_cast<uint16_t*>(np_smem + sh.sys_src);
-    for (int i = threadIdx.x; i <= t.m; i += blockDim.x) row_ptr[i] = t.row_ptr[i];
-    for (int i = threadIdx.x; i < t.n_edges; i += blockDim.x) { edge_var[i] = t.edge_var[i]; col_edge[i] = t.col_edge[i]; }
-    for (int i = threadIdx.x; i <= t.n; i += blockDim.x) col_ptr[i] = col_ptr_g[i];
+    const int n_slots = t.m * MAXR;
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) chk_var[i] = chk_var_g[i];
+    for (int i = threadIdx.x; i < t.n * 4; i += blockDim.x) var_edge[i] = var_edge_g[i];
+    for (int i = threadIdx.x; i < t.m; i += blockDim.x) chk_deg[i] = chk_deg_g[i];
     for (int i = threadIdx.x; i < t.n; i += blockDim.x) perm[i] = perm_g[i];
     for (int i = threadIdx.x; i < t.k; i += blockDim.x) sys_src[i] = t.sys_src[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char* mine = np_smem + sh.wave_base + size_t(wave) * sh.wave_stride;
-    double* msg = reinterpret_cast<double*>(mine);
-    double* rx = msg + t.n_edges;
-    uint8_t* est = reinterpret_cast<uint8_t*>(rx + t.n);
+    double* msg = reinterpret_cast<double*>(mine);   // n_slots messages + [n_slots] == 1.0 + [n_slots + 1] trash
+    double* rx = msg + n_slots + 2;                  // n channel LRs + rx[n] == 0 (dummy variable)
+    uint8_t* est = reinterpret_cast<uint8_t*>(rx + t.n + 1); // n hard decisions + est[n] == 0
     float* ybuf = reinterpret_cast<float*>(msg);
+    const int kOneSlot = n_slots, kTrashSlot = n_slots + 1;
     const int ncheck = t.n - t.k;
     const float s2 = sigma * sigma;
 
@@ -201,8 +212,8 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         unsigned bad = 0;
         for (int c = lane; c < t.m; c += kWave) {
             unsigned s = 0;
-            const int e1 = row_ptr[c + 1];
-            for (int e = row_ptr[c]; e < e1; e++) s ^= est[edge_var[e]];
+#pragma unroll
+            for (int j = 0; j < MAXR; j++) s ^= est[chk_var[c * MAXR + j]];
             bad |= s;
         }
         return __ballot(bad != 0) == 0ull;
@@ -272,51 +283,50 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                 est[v] = (y < 0) ? 1 : 0;
             }
         }
+        if (lane == 0) est[t.n] = 0;
         wave_sync();
         int nit = 0;
         if (!syndrome_ok()) {
             for (int v = lane; v < t.n; v += kWave) rx[v] = exp(double((-1 * 2 * ybuf[v]) / s2));
+            if (lane == 0) rx[t.n] = 0.0;
             wave_sync();
-            for (int e = lane; e < t.n_edges; e += kWave) msg[e] = rx[edge_var[e]];
+            for (int e = lane; e < n_slots; e += kWave) msg[e] = rx[chk_var[e]];
+            if (lane == 0) { msg[kOneSlot] = 1.0; msg[kTrashSlot] = 0.0; }
             wave_sync();
             while (nit < max_it) {
                 nit += 1;
                 // ---- update_chks: lane == check node
                 for (int c = lane; c < t.m; c += kWave) {
-                    const int lo = row_ptr[c], deg = row_ptr[c + 1] - lo;
+                    double* row = msg + c * MAXR;
                     double tt[MAXR];
 #pragma unroll
-                    for (int j = 0; j < MAXR; j++) {
-                        tt[j] = 1.0;
-                        if (j < deg) tt[j] = 2 / (1 + msg[lo + j]) - 1;
-                    }
+                    for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + row[j]) - 1;
                     double product = 1.0;
 #pragma unroll
-                    for (int j = 0; j < MAXR; j++)
-                        if (j < deg) product = product * tt[j];
+                    for (int j = 0; j < MAXR; j++) product = product * tt[j];
+                    const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
 #pragma unroll
                     for (int j = 0; j < MAXR; j++) {
-                        if (j < deg) {
-                            const double prd = product / tt[j];
-                            msg[lo + j] = (1 - prd) / (1 + prd);
-                        }
+                        const double prd = product / tt[j];
+                        const double val = (1 - prd) / (1 + prd);
+                        row[j] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
                     }
                 }
                 wave_sync();
                 // ---- update_vars + decision: lane == variable node
                 for (int v = lane; v < t.n; v += kWave) {
-                    const int lo = col_ptr[v], deg = col_ptr[v + 1] - lo;
-                    double rr[MAXC];
+                    const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
                     int ee[MAXC];
+                    double rr[MAXC];
                     double sum = rx[v];
 #pragma unroll
                     for (int i = 0; i < MAXC; i++) {
-                        ee[i] = 0; rr[i] = 1.0;
-                        if (i < deg) { ee[i] = col_edge[lo + i]; rr[i] = msg[ee[i]]; sum = sum * rr[i]; }
+                        ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
+                        rr[i] = msg[ee[i]];
+                        sum = sum * rr[i];
                     }
 #pragma unroll
-                    for (int i = 0; i < MAXC; i++)
-                        if (i < deg) msg[ee[i]] = sum / rr[i];
+                    for (int i = 0; i < MAXC; i++) msg[ee[i] == kOneSlot ? kTrashSlot : ee[i]] = sum / rr[i];
                     est[v] = (sum > 1) ? 1 : 0;
                 }
                 wave_sync();
@@ -369,11 +379,34 @@ int LdpcDecoder::upload()
     size_t o_ev = put(edge_var.data(), edge_var.size() * 2);
     size_t o_ip = put(inv_perm.data(), inv_perm.size() * 2);
     size_t o_ss = put(sys_src.data(), sys_src.size() * 2);
-    std::vector<uint16_t> col_ptr16 = to16(code.col_ptr), perm16 = to16(code.permute);
-    size_t o_cp = put(col_ptr16.data(), col_ptr16.size() * 2);
+    std::vector<uint16_t> perm16 = to16(code.permute);
     size_t o_pm = put(perm16.data(), perm16.size() * 2);
     const unsigned int zero = 0;
     size_t o_q = put(&zero, sizeof(zero));
+    // fixed-stride tables of the node-parallel kernel (see the kernel's comment)
+    const bool small_code = code.max_row_deg <= 6 && code.max_col_deg <= 3 && code.n <= 320; // kernel <6,3,5>
+    const int maxr = small_code ? 6 : 8;
+    const int n_slots = code.m * maxr;
+    std::vector<uint16_t> chk_var(size_t(n_slots), uint16_t(code.n));          // pad -> dummy variable n
+    std::vector<uint8_t> chk_deg(size_t(code.m), 0);
+    std::vector<int> slot_of_edge(size_t(code.n_edges), 0);                    // check-major edge -> padded slot
+    bool rows_full = true;
+    for (int c = 0; c < code.m; c++) {
+        const int deg = code.row_ptr[c + 1] - code.row_ptr[c];
+        chk_deg[c] = uint8_t(std::min(deg, 255));
+        if (deg != maxr) rows_full = false;
+        for (int j = 0; j < deg && j < maxr; j++) {
+            chk_var[size_t(c) * maxr + j] = uint16_t(code.edge_var[code.row_ptr[c] + j]);
+            slot_of_edge[code.row_ptr[c] + j] = c * maxr + j;
+        }
+    }
+    std::vector<uint16_t> var_edge(size_t(code.n) * 4, uint16_t(n_slots));     // pad -> the slot kept at 1.0
+    for (int v = 0; v < code.n; v++)
+        for (int i = code.col_ptr[v]; i < code.col_ptr[v + 1] && i - code.col_ptr[v] < 4; i++)
+            var_edge[size_t(v) * 4 + (i - code.col_ptr[v])] = uint16_t(slot_of_edge[code.col_edge[i]]);
+    size_t o_cv = put(chk_var.data(), chk_var.size() * 2);
+    size_t o_ve = put(var_edge.data(), var_edge.size() * 2);
+    size_t o_cd = put(chk_deg.data(), chk_deg.size());
     if (blob_) { (void)hipFree(blob_); blob_ = nullptr; }
     DTL_HIP_CHECK(hipMalloc(&blob_, host.size()));
     DTL_HIP_CHECK(hipMemcpy(blob_, host.data(), host.size(), hipMemcpyHostToDevice));
@@ -387,25 +420,33 @@ int LdpcDecoder::upload()
     t_.edge_var = reinterpret_cast<const uint16_t*>(b + o_ev);
     t_.inv_perm = reinterpret_cast<const uint16_t*>(b + o_ip);
     t_.sys_src = reinterpret_cast<const uint16_t*>(b + o_ss);
-    np_col_ptr_ = reinterpret_cast<const uint16_t*>(b + o_cp);
     np_perm_ = reinterpret_cast<const uint16_t*>(b + o_pm);
+    np_chk_var_ = reinterpret_cast<const uint16_t*>(b + o_cv);
+    np_var_edge_ = reinterpret_cast<const uint16_t*>(b + o_ve);
+    np_chk_deg_ = b + o_cd;
+    np_rows_full_ = rows_full;
+    np_maxr_ = maxr;
     np_queue_ = reinterpret_cast<unsigned int*>(b + o_q);
     // LDS plan of the node-parallel kernel: shared index tables + 16 per-wave slices
     {
         auto al = [](size_t v) { return (v + 15) & ~size_t(15); };
         size_t off = 0;
-        np_sh_.row_ptr = int(off); off = al(off + size_t(code.m + 1) * 2);
-        np_sh_.edge_var = int(off); off = al(off + size_t(code.n_edges) * 2);
-        np_sh_.col_ptr = int(off); off = al(off + size_t(code.n + 1) * 2);
-        np_sh_.col_edge = int(off); off = al(off + size_t(code.n_edges) * 2);
+        np_sh_.chk_var = int(off); off = al(off + size_t(n_slots) * 2);
+        np_sh_.var_edge = int(off); off = al(off + size_t(code.n) * 4 * 2);
+        np_sh_.chk_deg = int(off); off = al(off + size_t(code.m));
         np_sh_.perm = int(off); off = al(off + size_t(code.n) * 2);
         np_sh_.sys_src = int(off); off = al(off + size_t(code.k) * 2);
         np_sh_.wave_base = int(off);
-        np_sh_.wave_stride = int(al(lds_bytes()));
+        // per-wave slice: padded message slots + 2, channel LRs + 1, hard decisions + 1
+        np_sh_.wave_stride = int(al(size_t(n_slots + 2) * 8 + size_t(code.n + 1) * 8 + size_t(code.n + 1)));
         np_lds_ = off + size_t(kNpWaves) * np_sh_.wave_stride;
-        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && np_lds_ <= 160 * 1024;
+        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && n_slots + 2 < 65535 &&
+                 np_lds_ <= 160 * 1024;
         if (np_ok_) {
-            for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5>), reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8>) })
+            for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, true>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, false>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, true>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, false>) })
                 DTL_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(np_lds_)));
         }
     }
@@ -425,14 +466,14 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
     }
     if (np_ok_) {
         const int grid = int(std::min<size_t>((ncw + kNpWaves - 1) / kNpWaves, 256));
-        auto kern = (code.max_row_deg <= 6 && code.max_col_deg <= 3 && code.n <= 320) ? ldpc_bp_np_kernel<6, 3, 5>
-                                                                                         : ldpc_bp_np_kernel<8, 4, 8>;
+        auto kern = np_maxr_ == 6 ? (np_rows_full_ ? ldpc_bp_np_kernel<6, 3, 5, true> : ldpc_bp_np_kernel<6, 3, 5, false>)
+                                  : (np_rows_full_ ? ldpc_bp_np_kernel<8, 4, 8, true> : ldpc_bp_np_kernel<8, 4, 8, false>);
         // every wave stops at its first out-of-range ticket: the counter ends below n_chunks + #waves.
         // Large batches take 16 codewords per ticket (keeps the same-address atomics off the critical
         // path); small ones shrink the ticket so that all 4096 waves get work and the tail stays short.
         const int chunk = int(std::max<size_t>(1, std::min<size_t>(kNpChunk, ncw / (size_t(grid) * kNpWaves * 4))));
         DTL_HIP_CHECK(hipMemsetAsync(np_queue_, 0, sizeof(unsigned int), stream));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_col_ptr_, np_perm_,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_chk_var_, np_var_edge_, np_chk_deg_, np_perm_,
                            d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, np_queue_, chunk);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
