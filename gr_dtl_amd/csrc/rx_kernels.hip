@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void trigger_angle_kernel(const cf32* __restric
 __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
                               const Candidate* __restrict__ cands, const CfoSegment* __restrict__ segs,
                               int n_segs, HeaderRec* __restrict__ recs, cf32* __restrict__ taps_out,
-                              uint8_t* __restrict__ hdr_bits_out)
+                              uint8_t* __restrict__ hdr_bits_out, int search_in_lds)
 {
     extern __shared__ unsigned char smem_raw[];
     const int N = t.fft_len, h = t.header_len, tid = threadIdx.x;
@@ -360,6 +360,7 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     float* gabs = reinterpret_cast<float*>(H + N);          // N/2+2 |B(g)| values
     uint8_t* bits = reinterpret_cast<uint8_t*>(gabs + N / 2 + 2); // hdr_bits
     cf32* tw = reinterpret_cast<cf32*>(bits + ((t.hdr_bits + 15) & ~15)); // N/2 twiddles
+    cf32* terms = tw + N / 2;                                // n_g x (n_act + 1) products of the offset search
     __shared__ int s_off;
 
     if (tid < N / 2) tw[tid] = t.twiddle[tid];
@@ -370,16 +371,40 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N]
     auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + ((k + N / 2) & (N - 1))]; };
 
-    // get_carr_offset: B(g) = sum_k conj(y1[k+g]) * conj(corr_v[k]) * y2[k+g], first maximum wins
+    // get_carr_offset: B(g) = sum_k conj(y1[k+g]) * conj(corr_v[k]) * y2[k+g], first maximum wins.
+    // The reference adds the terms in carrier order in float, so the sum of one offset g is a serial chain;
+    // what can be shared is the work inside it: all lanes form the products (lane == participating carrier,
+    // half of the workgroup per offset parity) and park them in LDS, then one lane per offset only adds.
     const int n_g = (t.g_max - t.g_min) / 2 + 1;
-    for (int gi = tid; gi < n_g; gi += blockDim.x) {
-        const int g = t.g_min + 2 * gi;
-        cf32 acc = { 0.0f, 0.0f };
-        for (int k = 0; k < N; k++) {
-            const cf32 cv = t.corr_v[k];
-            if (cnonzero(cv)) acc = cadd(acc, cmul(cmul(cconj(ysh(0, k + g)), cconj(cv)), ysh(1, k + g)));
+    const int n_act = t.n_sync_act;
+    if (search_in_lds) {
+        const int per = n_act <= N / 2 ? N / 2 : N;          // lanes reserved per offset
+        const int groups = N / per, grp = tid / per, a = tid - grp * per;
+        if (a < n_act) {
+            const int k = t.sync_act[a];
+            const cf32 cvc = cconj(t.corr_v[k]);
+            for (int gi = grp; gi < n_g; gi += groups) {
+                const int g = t.g_min + 2 * gi;
+                terms[gi * (n_act + 1) + a] = cmul(cmul(cconj(ysh(0, k + g)), cvc), ysh(1, k + g));
+            }
         }
-        gabs[gi] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+        __syncthreads();
+        if (tid < n_g) {
+            cf32 acc = { 0.0f, 0.0f };
+            const cf32* row = terms + tid * (n_act + 1);
+            for (int i = 0; i < n_act; i++) acc = cadd(acc, row[i]);
+            gabs[tid] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+        }
+    } else {
+        for (int gi = tid; gi < n_g; gi += blockDim.x) {
+            const int g = t.g_min + 2 * gi;
+            cf32 acc = { 0.0f, 0.0f };
+            for (int k = 0; k < N; k++) {
+                const cf32 cv = t.corr_v[k];
+                if (cnonzero(cv)) acc = cadd(acc, cmul(cmul(cconj(ysh(0, k + g)), cconj(cv)), ysh(1, k + g)));
+            }
+            gabs[gi] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -909,11 +934,25 @@ int launch_trigger_angle(const cf32* iq, int64_t n, int N, const int64_t* trig, 
     return DTL_OK;
 }
 
+static size_t header_search_bytes(const RxTables& t)
+{
+    const int n_g = (t.g_max - t.g_min) / 2 + 1;
+    return size_t(n_g) * (t.n_sync_act + 1) * sizeof(cf32);
+}
+
+// the products of the offset search live in LDS when they are few enough to leave room for several workgroups
+// per CU (and one lane per offset exists); otherwise each offset's lane forms its own products
+static bool header_search_in_lds(const RxTables& t)
+{
+    const int n_g = (t.g_max - t.g_min) / 2 + 1;
+    return n_g <= t.fft_len && t.n_sync_act > 0 && header_search_bytes(t) <= 28 * 1024;
+}
+
 size_t header_lds_bytes(const RxTables& t)
 {
     size_t b = size_t(2 + t.header_len + 1) * t.fft_len * sizeof(cf32) + size_t(t.fft_len) * sizeof(cf32) +
                size_t(t.fft_len / 2 + 2) * sizeof(float) + size_t((t.hdr_bits + 15) & ~15) +
-               size_t(t.fft_len / 2) * sizeof(cf32);
+               size_t(t.fft_len / 2) * sizeof(cf32) + (header_search_in_lds(t) ? header_search_bytes(t) : 0);
     return (b + 15) & ~size_t(15);
 }
 
@@ -922,8 +961,15 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
                   hipStream_t st)
 {
     if (n_cand <= 0) return DTL_OK;
-    hipLaunchKernelGGL(header_kernel, dim3(n_cand), dim3(t.fft_len), header_lds_bytes(t), st, t, iq, n, cands,
-                       segs, n_segs, recs, taps, hdr_bits);
+    const size_t lds = header_lds_bytes(t);
+    static size_t attr_lds = 64 * 1024;
+    if (lds > attr_lds) {
+        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(header_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(header_kernel, dim3(n_cand), dim3(t.fft_len), lds, st, t, iq, n, cands,
+                       segs, n_segs, recs, taps, hdr_bits, header_search_in_lds(t) ? 1 : 0);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

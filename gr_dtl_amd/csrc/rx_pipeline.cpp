@@ -504,6 +504,9 @@ int Receiver::upload_tables()
     const size_t o_pm = put(pmask.data(), pmask.size());
     const size_t o_pv = put(pval.data(), pval.size() * sizeof(cf32));
     const size_t o_cv = put(corr.data(), corr.size() * sizeof(cf32));
+    std::vector<uint16_t> sync_act; // carriers that take part in the integer-offset search (corr_v != 0), ascending
+    for (int i = 0; i < N; i++) if (corr[i].re != 0 || corr[i].im != 0) sync_act.push_back(uint16_t(i));
+    const size_t o_sa = put(sync_act.data(), std::max<size_t>(sync_act.size(), 1) * 2);
     const size_t o_rf = put(ref.data(), ref.size() * sizeof(cf32));
     const size_t o_pt = put(pts.data(), pts.size() * sizeof(cf32));
     int rc = tab_blob_.ensure(blob.size());
@@ -526,6 +529,8 @@ int Receiver::upload_tables()
     tab_.pilot_mask = b + o_pm;
     tab_.pilot_val = reinterpret_cast<const cf32*>(b + o_pv);
     tab_.corr_v = reinterpret_cast<const cf32*>(b + o_cv);
+    tab_.sync_act = reinterpret_cast<const uint16_t*>(b + o_sa);
+    tab_.n_sync_act = int(sync_act.size());
     tab_.ref_sym = reinterpret_cast<const cf32*>(b + o_rf);
     tab_.cnst_pts = reinterpret_cast<const cf32*>(b + o_pt);
     for (auto& d : decoders_)

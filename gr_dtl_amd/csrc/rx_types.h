@@ -30,6 +30,8 @@ struct RxTables {
     const uint8_t* pilot_mask; // n_pilot_sets x fft_len
     const cf32* pilot_val;     // n_pilot_sym_sets x fft_len
     const cf32* corr_v;        // fft_len : sync2 / sync1 on sync1's non-zero carriers
+    const uint16_t* sync_act;  // n_sync_act : the carriers with corr_v != 0, ascending
+    int n_sync_act;
     const cf32* ref_sym;       // fft_len : sync word 2
     const cf32* cnst_pts;      // 5 x 16 constellation points (index = constellation_type_t)
 };
