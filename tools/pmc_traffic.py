@@ -29,7 +29,7 @@ def per_kernel_counter(root, counter):
                         a = acc.setdefault(key, [0.0, 0])
                         a[0] += float(row["Counter_Value"])
                         a[1] += 1
-    return {k: v[0] / v[1] for k, v in acc.items() if v[1]}
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
 
 
 def main():
@@ -45,11 +45,14 @@ def main():
     fetch = per_kernel_counter(os.path.join(out_dir, "fetch"), "FETCH_SIZE")
     write = per_kernel_counter(os.path.join(out_dir, "write"), "WRITE_SIZE")
     kernels = {}
+    steps = fetch.get("ldpc_bp", (0, 1))[1]      # the LDPC kernel is launched once per step
     for k in KERNELS:
         if k in fetch or k in write:
-            fb = fetch.get(k, 0.0) * 1024 * 2   # FETCH_SIZE counts KiB; gfx950 reports half (MI355X_MICROARCH.md)
-            wb = write.get(k, 0.0) * 1024
-            kernels[k] = {"fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+            fb = fetch.get(k, (0.0, 0))[0] * 1024 * 2   # FETCH_SIZE counts KiB; gfx950 reports half (MI355X_MICROARCH.md)
+            wb = write.get(k, (0.0, 0))[0] * 1024
+            per_step = fetch.get(k, write.get(k))[1] / max(steps, 1)   # phases A/B and the sync stage run in 4 chunks
+            kernels[k] = {"fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
+                          "launches_per_step": per_step, "hbm_bytes_per_step": (fb + wb) * per_step}
     doc = {"workload": workload,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x1024 B x2 (gfx950 half-count "
                    "correction of MI355X_MICROARCH.md), WRITE_SIZE x1024 B; per launch averages",
