@@ -75,50 +75,70 @@ __device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, 
     return float(ph);
 }
 
-// Load OFDM symbols `symA` and `symB` (symB < 0: none) of the frame cut at `trigger` (delay N+cp,
-// CP stripped, fine-CFO derotated) into bufA / bufB in bit-reversed order, then radix-2 DIT FFTs in
-// place.  blockDim.x == N: the lower half of the workgroup runs the butterflies of A, the upper
-// half those of B, so every lane works in every stage.  tw: N/2 twiddles staged in LDS.
-__device__ __forceinline__ void load_and_fft2(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
-                                              int64_t trigger, int symA, int symB, const CfoSegment* segs,
-                                              int n_segs, int seg, cf32* bufA, cf32* bufB, const cf32* tw)
+// Load up to four consecutive OFDM symbols (sym0 .. sym0+n_sym-1) of the frame cut at `trigger` (delay N+cp,
+// CP stripped, fine-CFO derotated) into the rows buf + u*N in bit-reversed order, then radix-2 DIT FFTs in
+// place.  blockDim.x == N.  Two butterfly stages are executed per LDS round trip: a thread owns the four
+// elements {i, i+h, i+2h, i+3h} of one symbol, runs the two span-h butterflies of stage s and the two span-2h
+// butterflies of stage s+1 on them in registers (the same operations, in the same order per butterfly, as two
+// separate passes -- bit-identical), so the N/4 groups of four symbols keep all N lanes busy with half the
+// LDS traffic and half the barriers.  An odd last stage runs as a plain pass.  tw: N/2 twiddles in LDS.
+__device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
+                                              int64_t trigger, int sym0, int n_sym, const CfoSegment* segs,
+                                              int n_segs, int seg, cf32* buf, const cf32* tw)
 {
     const int N = t.fft_len, P = N + t.cp_len;
     const int tid = threadIdx.x;
     const float sens = float(-2.0 / N);
     const int br = t.bitrev[tid];
-    {
+    for (int u = 0; u < n_sym; u++) {
         // mixed[i] = r[i - (N+cp)] * osc[i]; symbol sample index i = trigger + sym*P + cp + tid
-        const int64_t i = trigger + int64_t(symA) * P + t.cp_len + tid;
+        const int64_t i = trigger + int64_t(sym0 + u) * P + t.cp_len + tid;
         const int64_t src = i - P;
         cf32 v = { 0.0f, 0.0f };
         if (src >= 0 && src < n_samples) v = iq[src];
-        bufA[br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
-    }
-    if (symB >= 0) {
-        const int64_t i = trigger + int64_t(symB) * P + t.cp_len + tid;
-        const int64_t src = i - P;
-        cf32 v = { 0.0f, 0.0f };
-        if (src >= 0 && src < n_samples) v = iq[src];
-        bufB[br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
+        buf[u * N + br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
     }
     __syncthreads();
-    const int hN = N / 2;
-    const bool upper = tid >= hN;
-    cf32* buf = upper ? bufB : bufA;
-    const int bt = upper ? tid - hN : tid;
-    const bool active = !upper || symB >= 0;
     const int logN = __ffs(N) - 1;
-    for (int st = 0; st < logN; st++) { // stage st: butterflies of span len = 2^(st+1); shifts, not divisions
-        const int half = 1 << st;
+    const int u = tid >> (logN - 2), q = tid & ((N >> 2) - 1); // symbol of the batch, group of four inside it
+    cf32* x = buf + u * N;
+    const bool active = u < n_sym;
+    int st = 0;
+    for (; st + 1 < logN; st += 2) {
         if (active) {
-            const int grp = bt >> st, k = bt & (half - 1);
-            const int a = (grp << (st + 1)) + k, b = a + half;
-            const cf32 w = tw[k << (logN - st - 1)];
-            const cf32 u = buf[a];
-            const cf32 vv = cmul(buf[b], w);
-            buf[a] = cadd(u, vv);
-            buf[b] = csub(u, vv);
+            const int h = 1 << st;
+            const int k = q & (h - 1);
+            const int i0 = ((q >> st) << (st + 2)) + k, i1 = i0 + h, i2 = i1 + h, i3 = i2 + h;
+            // stage st: (i0,i1) and (i2,i3), twiddle W^(k N / 2h)
+            const cf32 w0 = tw[k << (logN - st - 1)];
+            cf32 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
+            cf32 v = cmul(a1, w0);
+            a1 = csub(a0, v); a0 = cadd(a0, v);
+            v = cmul(a3, w0);
+            a3 = csub(a2, v); a2 = cadd(a2, v);
+            // stage st+1: (i0,i2) with W^(k N / 4h), (i1,i3) with W^((k+h) N / 4h)
+            const cf32 w1 = tw[k << (logN - st - 2)], w2 = tw[(k + h) << (logN - st - 2)];
+            v = cmul(a2, w1);
+            a2 = csub(a0, v); a0 = cadd(a0, v);
+            v = cmul(a3, w2);
+            a3 = csub(a1, v); a1 = cadd(a1, v);
+            x[i0] = a0; x[i1] = a1; x[i2] = a2; x[i3] = a3;
+        }
+        __syncthreads();
+    }
+    if (st < logN) { // log2(N) odd: one plain stage, N/2 butterflies per symbol = two per thread
+        if (active) {
+            const int half = 1 << st;
+            for (int r = 0; r < 2; r++) {
+                const int bt = q + r * (N >> 2);
+                const int grp = bt >> st, k = bt & (half - 1);
+                const int a = (grp << (st + 1)) + k, b = a + half;
+                const cf32 w = tw[k << (logN - st - 1)];
+                const cf32 uu = x[a];
+                const cf32 vv = cmul(x[b], w);
+                x[a] = cadd(uu, vv);
+                x[b] = csub(uu, vv);
+            }
         }
         __syncthreads();
     }
@@ -365,9 +385,8 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 
     if (tid < N / 2) tw[tid] = t.twiddle[tid];
     const Candidate cd = cands[blockIdx.x];
-    for (int s = 0; s < 2 + h; s += 2)
-        load_and_fft2(t, iq, n_samples, cd.trigger, s, (s + 1 < 2 + h) ? s + 1 : -1, segs, n_segs, cd.seg,
-                      Y + size_t(s) * N, Y + size_t(s + 1) * N, tw);
+    for (int s = 0; s < 2 + h; s += 4)
+        load_and_fft4(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, cd.seg, Y + size_t(s) * N, tw);
     // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N]
     auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + ((k + N / 2) & (N - 1))]; };
 
@@ -549,8 +568,8 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
 {
     extern __shared__ unsigned char smem_raw[];
     const int N = t.fft_len, L = t.frame_length, tid = threadIdx.x, h = t.header_len;
-    cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // 2 x N : FFT scratch (two symbols per pass)
-    cf32* frame = buf + 2 * N;                        // L x N : shifted/derotated FFT output -> soft symbols
+    cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // 4 x N : FFT scratch (four symbols per batch)
+    cf32* frame = buf + 4 * N;                        // L x N : shifted/derotated FFT output -> soft symbols
     Welford* wred = reinterpret_cast<Welford*>(frame + size_t(L) * N); // blockDim/64 partials
     cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64);          // N/2 twiddles
     if (tid < N / 2) tw[tid] = t.twiddle[tid];
@@ -563,12 +582,11 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
     // zero fill of the integer-CFO shift (:154-166)
     if (off < 0) { for (int p = tid; p < -off; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
     else { for (int p = total - off + tid; p < total; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
-    for (int i0 = 0; i0 < L; i0 += 2) {
-        const bool two = i0 + 1 < L;
-        load_and_fft2(t, iq, n_samples, fd.trigger, 2 + h + i0, two ? 2 + h + i0 + 1 : -1, segs, n_segs, fd.seg,
-                      buf, buf + N, tw);
+    for (int i0 = 0; i0 < L; i0 += 4) {
+        const int nb = min(4, L - i0);
+        load_and_fft4(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, fd.seg, buf, tw);
         // out[p - off] = in[p], then out *= expj(-2 pi off cp / N (sym+1)) with sym of the destination
-        for (int u = 0; u < (two ? 2 : 1); u++) {
+        for (int u = 0; u < nb; u++) {
             const int p = (i0 + u) * N + tid;
             const int dst = p - off;
             if (dst >= 0 && dst < total) {
@@ -976,7 +994,7 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
 
 size_t payload_lds_bytes(const RxTables& t)
 {
-    size_t b = size_t(2 * t.fft_len) * sizeof(cf32) + size_t(t.frame_length) * t.fft_len * sizeof(cf32) +
+    size_t b = size_t(4 * t.fft_len) * sizeof(cf32) + size_t(t.frame_length) * t.fft_len * sizeof(cf32) +
                size_t((t.fft_len + 63) / 64) * sizeof(Welford) + size_t(t.fft_len / 2) * sizeof(cf32);
     return (b + 15) & ~size_t(15);
 }
