@@ -59,16 +59,40 @@ __device__ __forceinline__ cf32 expj(float phase)
 constexpr double kPi = 3.14159265358979323846;
 
 // Oscillator phase at stream index i: frequency_modulator_fc(-2/N) integrating the held angle.
-__device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, int n_segs, int seg,
+// The segments a frame can touch are loaded once per workgroup (uniform values): the one active at the frame's
+// trigger and its successor; an index beyond the successor's end takes the general walk.
+struct SegWindow {
+    CfoSegment a, b;
+    int64_t c_start;   // start of the segment after b (or the largest index)
+    int seg;           // index of a (-1: before the first trigger)
+    bool has_a, has_b;
+};
+
+__device__ __forceinline__ SegWindow seg_window(const CfoSegment* __restrict__ segs, int n_segs, int seg)
+{
+    SegWindow w{};
+    w.seg = seg;
+    w.has_a = seg >= 0 && seg < n_segs;
+    if (w.has_a) w.a = segs[seg];
+    w.has_b = seg + 1 >= 0 && seg + 1 < n_segs;
+    if (w.has_b) w.b = segs[seg + 1];
+    w.c_start = (seg + 2 >= 0 && seg + 2 < n_segs) ? segs[seg + 2].start : 0x7fffffffffffffffLL;
+    return w;
+}
+
+__device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, int n_segs, const SegWindow& w,
                                            int64_t i, float sens)
 {
-    while (seg + 1 < n_segs && segs[seg + 1].start <= i) seg++;
-    double ph;
-    if (seg < 0 || segs[seg].start > i) {
-        ph = 0.0; // before the first trigger the held angle is 0
-    } else {
+    double ph = 0.0; // before the first trigger the held angle is 0
+    if (i >= w.c_start) {
+        int seg = w.seg + 2;
+        while (seg + 1 < n_segs && segs[seg + 1].start <= i) seg++;
         const CfoSegment s = segs[seg];
         ph = s.phase0 + double(sens * s.angle) * double(i - s.start + 1);
+    } else if (w.has_b && w.b.start <= i) {
+        ph = w.b.phase0 + double(sens * w.b.angle) * double(i - w.b.start + 1);
+    } else if (w.has_a && w.a.start <= i) {
+        ph = w.a.phase0 + double(sens * w.a.angle) * double(i - w.a.start + 1);
     }
     // wrap to [-pi, pi): ph - 2 pi floor((ph + pi) / 2 pi)
     ph -= (2.0 * kPi) * floor((ph + kPi) * (1.0 / (2.0 * kPi)));
@@ -84,7 +108,7 @@ __device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, 
 // LDS traffic and half the barriers.  An odd last stage runs as a plain pass.  tw: N/2 twiddles in LDS.
 __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
                                               int64_t trigger, int sym0, int n_sym, const CfoSegment* segs,
-                                              int n_segs, int seg, cf32* buf, const cf32* tw)
+                                              int n_segs, const SegWindow& seg, cf32* buf, const cf32* tw)
 {
     const int N = t.fft_len, P = N + t.cp_len;
     const int tid = threadIdx.x;
@@ -385,8 +409,9 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 
     if (tid < N / 2) tw[tid] = t.twiddle[tid];
     const Candidate cd = cands[blockIdx.x];
+    const SegWindow sw = seg_window(segs, n_segs, cd.seg);
     for (int s = 0; s < 2 + h; s += 4)
-        load_and_fft4(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, cd.seg, Y + size_t(s) * N, tw);
+        load_and_fft4(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, sw, Y + size_t(s) * N, tw);
     // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N]
     auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + ((k + N / 2) & (N - 1))]; };
 
@@ -579,12 +604,13 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
     const int off = fd.carr_offset;
     const int total = L * N;
 
+    const SegWindow sw = seg_window(segs, n_segs, fd.seg);
     // zero fill of the integer-CFO shift (:154-166)
     if (off < 0) { for (int p = tid; p < -off; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
     else { for (int p = total - off + tid; p < total; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
     for (int i0 = 0; i0 < L; i0 += 4) {
         const int nb = min(4, L - i0);
-        load_and_fft4(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, fd.seg, buf, tw);
+        load_and_fft4(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
         // out[p - off] = in[p], then out *= expj(-2 pi off cp / N (sym+1)) with sym of the destination
         for (int u = 0; u < nb; u++) {
             const int p = (i0 + u) * N + tid;
