@@ -295,21 +295,56 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             wave_sync();
             while (nit < max_it) {
                 nit += 1;
-                // ---- update_chks: lane == check node
-                for (int c = lane; c < t.m; c += kWave) {
-                    double* row = msg + c * MAXR;
-                    double tt[MAXR];
+                // ---- update_chks: lane == check node.  When the last pass would fill at most half of the wave
+                // (148 checks = 64 + 64 + 20), it runs with TWO lanes per check instead, each owning half of the
+                // row: half the divisions per lane, and the row product is still formed in the reference's
+                // order (the even lane multiplies its factors, hands the partial product to the odd lane, which
+                // multiplies its own on top and hands the result back).
+                int c0 = 0;
+                for (; c0 + kWave <= t.m || t.m - c0 > kWave / 2; c0 += kWave) {
+                    const int c = c0 + lane;
+                    if (c < t.m) {
+                        double* row = msg + c * MAXR;
+                        double tt[MAXR];
 #pragma unroll
-                    for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + row[j]) - 1;
-                    double product = 1.0;
+                        for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + row[j]) - 1;
+                        double product = 1.0;
 #pragma unroll
-                    for (int j = 0; j < MAXR; j++) product = product * tt[j];
-                    const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
+                        for (int j = 0; j < MAXR; j++) product = product * tt[j];
+                        const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
 #pragma unroll
-                    for (int j = 0; j < MAXR; j++) {
-                        const double prd = product / tt[j];
-                        const double val = (1 - prd) / (1 + prd);
-                        row[j] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
+                        for (int j = 0; j < MAXR; j++) {
+                            const double prd = product / tt[j];
+                            const double val = (1 - prd) / (1 + prd);
+                            row[j] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
+                        }
+                    }
+                }
+                if (c0 < t.m) {
+                    constexpr int HR = MAXR / 2;
+                    const int c = c0 + (lane >> 1);
+                    const bool upper = lane & 1;
+                    const bool valid = c < t.m;
+                    double* row = msg + (valid ? c : 0) * MAXR + (upper ? HR : 0);
+                    double tt[HR];
+#pragma unroll
+                    for (int j = 0; j < HR; j++) tt[j] = 2 / (1 + row[j]) - 1;
+                    double part = 1.0;
+#pragma unroll
+                    for (int j = 0; j < HR; j++) part = part * tt[j];             // even lane: ((1 t0) t1) t2
+                    double product = __shfl_xor(part, 1);                         // odd lane: the even lane's partial
+#pragma unroll
+                    for (int j = 0; j < HR; j++) product = product * tt[j];       // odd lane: ... t3) t4) t5
+                    const double back = __shfl_xor(product, 1);                   // even lane: the finished product
+                    if (!upper) product = back;
+                    const int deg = ROWS_FULL ? MAXR : int(chk_deg[valid ? c : 0]);
+                    if (valid) {
+#pragma unroll
+                        for (int j = 0; j < HR; j++) {
+                            const double prd = product / tt[j];
+                            const double val = (1 - prd) / (1 + prd);
+                            row[j] = (ROWS_FULL || (upper ? HR : 0) + j < deg) ? val : 0.0;
+                        }
                     }
                 }
                 wave_sync();
