@@ -211,15 +211,15 @@ __device__ uint32_t crc_bits(const uint8_t* data, int len, int nbits, uint32_t p
 // B = the rounding boundary between thr and its predecessor (25 significant bits), num >= B * den
 // is exact in double (49-bit product) and decides the same way for every finite den > 0.
 // ------------------------------------------------------------------------------------------
-constexpr int kSyncThreads = 256;
-constexpr int kSyncStrip = 16;
-constexpr int kSyncTile = kSyncThreads * kSyncStrip;
-static_assert(kSyncTile == kSyncTileSamples, "the stream carry is aligned to the sync tile");
+constexpr int kSyncTile = kSyncTileSamples;   // the stream carry is aligned to the sync tile
 
-__device__ __forceinline__ int sync_pad(int j) { return j + (j >> 4); }
+// strip length R (outputs per thread): 8 with 512 threads for N <= 512 (half the registers per thread, twice the
+// waves in flight), 16 with 256 threads for N = 1024 (the N/R history strips must fit one wave)
+template <int R>
+__device__ __forceinline__ int sync_pad(int j) { return j + (j / R); }
 
-template <bool WITH_METRIC>
-__global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
+template <bool WITH_METRIC, int R>
+__global__ __launch_bounds__(kSyncTile / R) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
                                                                  int64_t m_begin, int N, float thr,
                                                                  unsigned long long* __restrict__ edges,
                                                                  unsigned int* __restrict__ n_edges,
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
                                                                  float* __restrict__ metric_out)
 {
     extern __shared__ double sync_smem[];
-    constexpr int R = kSyncStrip;
+    constexpr int kSyncThreads = kSyncTile / R;
     const int half = N / 2;
     const int nh = N / R;                       // history strips in front of the tile
     const int hw = half / R;                    // strips per P window
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
         const int64_t j = b0 + q;
         cf32 v = { 0.0f, 0.0f };
         if (j >= 0 && j < n) v = iq[j];
-        raw[sync_pad(q)] = v;
+        raw[sync_pad<R>(q)] = v;
     }
     __syncthreads();
 
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
         const int base = half + (nh + tid) * R;
 #pragma unroll
         for (int s = 0; s < R; s++) {
-            const cf32 a = raw[sync_pad(base + s)], b = raw[sync_pad(base + s - half)];
+            const cf32 a = raw[sync_pad<R>(base + s)], b = raw[sync_pad<R>(base + s - half)];
             cr[s] = a.re * b.re + a.im * b.im;
             ci[s] = a.im * b.re - a.re * b.im;
             eh[s] = 0.5f * (a.re * a.re + a.im * a.im);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
         const int base = half + tid * R;
 #pragma unroll
         for (int s = 0; s < R; s++) {
-            const cf32 a = raw[sync_pad(base + s)], b = raw[sync_pad(base + s - half)];
+            const cf32 a = raw[sync_pad<R>(base + s)], b = raw[sync_pad<R>(base + s - half)];
             hr += double(a.re * b.re + a.im * b.im);
             hi += double(a.im * b.re - a.re * b.im);
             he += double(0.5f * (a.re * a.re + a.im * a.im));
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kSyncThreads) void sync_edges_kernel(const cf32* __
     const int rb_new = N + half + tid * R;      // raw index of r[m0]
 #pragma unroll
     for (int s = 0; s < R; s++) {
-        const cf32 oa = raw[sync_pad(rb_new + s - half)], ob = raw[sync_pad(rb_new + s - N)];
+        const cf32 oa = raw[sync_pad<R>(rb_new + s - half)], ob = raw[sync_pad<R>(rb_new + s - N)];
         const float ocr = oa.re * ob.re + oa.im * ob.im, oci = oa.im * ob.re - oa.re * ob.im;
         const float oeh = 0.5f * (ob.re * ob.re + ob.im * ob.im);
         Wr = (Wr + double(cr[s])) - double(ocr);
@@ -947,24 +947,25 @@ int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int N, float t
                       unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st)
 {
     if (m_begin < 0 || m_begin > n) return DTL_ERR_INVALID_ARG;
-    if (N < 64 || (N % (2 * kSyncStrip)) != 0 || N / kSyncStrip > 64) return DTL_ERR_UNSUPPORTED; // history strips live in one wave
+    const int R = N <= 512 ? 8 : 16;
+    if (N < 64 || (N % (2 * R)) != 0 || N / R > 64) return DTL_ERR_UNSUPPORTED; // history strips live in one wave
+    const int threads = kSyncTile / R;
     const int n_raw = kSyncTile + N + N / 2;
-    const size_t lds = size_t(N / kSyncStrip + kSyncThreads) * 3 * sizeof(double) + size_t(n_raw + n_raw / 16 + 2) * sizeof(cf32);
+    const size_t lds = size_t(N / R + threads) * 3 * sizeof(double) + size_t(n_raw + n_raw / R + 2) * sizeof(cf32);
     const int64_t grid = (n + kSyncTile - 1) / kSyncTile - m_begin / kSyncTile;
     if (grid <= 0) return DTL_OK;
-    static size_t attr_lds[2] = { 64 * 1024, 64 * 1024 };
-    const int which = metric_out ? 1 : 0;
-    const void* fn = which ? reinterpret_cast<const void*>(sync_edges_kernel<true>) : reinterpret_cast<const void*>(sync_edges_kernel<false>);
+    using Kern = void (*)(const cf32*, int64_t, int64_t, int, float, unsigned long long*, unsigned int*, unsigned int, float*);
+    const int which = (metric_out ? 1 : 0) + (R == 16 ? 2 : 0);
+    static const Kern kerns[4] = { sync_edges_kernel<false, 8>, sync_edges_kernel<true, 8>, sync_edges_kernel<false, 16>,
+                                   sync_edges_kernel<true, 16> };
+    static size_t attr_lds[4] = { 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024 };
     if (lds > attr_lds[which]) {
-        DTL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[which]),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         attr_lds[which] = lds;
     }
-    if (metric_out)
-        hipLaunchKernelGGL(sync_edges_kernel<true>, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, m_begin, N, thr,
-                           edges, n_edges, max_edges, metric_out);
-    else
-        hipLaunchKernelGGL(sync_edges_kernel<false>, dim3((unsigned)grid), dim3(kSyncThreads), lds, st, iq, n, m_begin, N, thr,
-                           edges, n_edges, max_edges, metric_out);
+    hipLaunchKernelGGL(kerns[which], dim3((unsigned)grid), dim3(threads), lds, st, iq, n, m_begin, N, thr, edges, n_edges,
+                       max_edges, metric_out);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }
