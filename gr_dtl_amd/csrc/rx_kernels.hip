@@ -788,17 +788,37 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
 // K11: per transport block -- repack decoded bits to bytes (LSB first), CRC-32 verify
 // (ofdm_adaptive_fec_decoder_impl.cc:161-181), average iteration count (tb_decoder.cc:191).
 // ------------------------------------------------------------------------------------------
+// CRC-32 register after appending k zero bytes: the "append 2^j zero bytes" maps are linear over GF(2) and
+// given as 32 columns each (zmat[j * 32 + b] = image of bit b); binary expansion of k.
+__device__ __forceinline__ uint32_t crc32_shift(uint32_t v, unsigned k, const uint32_t* __restrict__ zmat)
+{
+    for (int j = 0; k; j++, k >>= 1) {
+        if (k & 1u) {
+            const uint32_t* m = zmat + j * 32;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < 32; b++) acc ^= ((v >> b) & 1u) ? m[b] : 0u;
+            v = acc;
+        }
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__ tbs, int n_tbs,
                                                      const uint8_t* __restrict__ bits,
                                                      const int32_t* __restrict__ nit,
                                                      uint8_t* __restrict__ staging, int stride,
-                                                     TbResult* __restrict__ res)
+                                                     TbResult* __restrict__ res, const uint32_t* __restrict__ zmat_g)
 {
-    // LDS: 4 x 256-entry CRC-32 tables (slicing-by-4, reflected polynomial 0xEDB88320 == the
-    // reference's crc(32, 0x04C11DB7, ~0, ~0, refin, refout)) + the TB's packed bytes
+    // CRC-32 (reflected polynomial 0xEDB88320 == the reference's crc(32, 0x04C11DB7, ~0, ~0, refin, refout)) of
+    // the TB's bytes, computed by all 64 lanes: the register update is linear, so every lane runs the byte-wise
+    // table recurrence over its own slice from a zero register, moves the result past the bytes that follow its
+    // slice with the zero-append maps, and the XOR of all lanes plus the moved initial value is the CRC.
+    // LDS: 256-entry table, 16 x 32 map columns, the TB's packed bytes.
     extern __shared__ uint32_t tb_smem[];
-    uint32_t* T = tb_smem;                                   // T[k*256 + i]
-    uint8_t* bytes_l = reinterpret_cast<uint8_t*>(tb_smem + 1024);
+    uint32_t* T = tb_smem;
+    uint32_t* zmat = tb_smem + 256;
+    uint8_t* bytes_l = reinterpret_cast<uint8_t*>(tb_smem + 256 + 16 * 32);
     const int tb = blockIdx.x;
     if (tb >= n_tbs) return;
     const int lane = threadIdx.x;
@@ -807,22 +827,14 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
         for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
         T[i] = c;
     }
-    __syncthreads();
-    for (int i = lane; i < 256; i += 64) {
-        uint32_t c = T[i];
-        for (int k = 1; k < 4; k++) {
-            c = T[c & 0xFF] ^ (c >> 8);
-            T[k * 256 + i] = c;
-        }
-    }
+    for (int i = lane; i < 16 * 32; i += 64) zmat[i] = zmat_g[i];
     const TbDesc d = tbs[tb];
     uint8_t* bytes = staging + size_t(tb) * stride;
     const int n_bytes = int(d.n_bits / 8);
     for (int b = lane; b < n_bytes; b += 64) {
         const unsigned long long w = *reinterpret_cast<const unsigned long long*>(bits + size_t(d.bits_off) + size_t(b) * 8);
-        unsigned v = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) v |= unsigned((w >> (8 * j)) & 1ull) << j;   // repack(1,8) LSB first
+        // repack(1,8) LSB first: bit j of the byte is the LSB of input byte j
+        const unsigned v = unsigned(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
         bytes_l[b] = uint8_t(v);
         bytes[b] = uint8_t(v);
     }
@@ -830,24 +842,24 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
     for (unsigned c = lane; c < d.n_cw; c += 64) it_sum += nit[d.cw_first + c];
     for (int o = 32; o > 0; o >>= 1) it_sum += __shfl_down(it_sum, o);
     __syncthreads();
+    int ok = 0;
+    if (n_bytes >= 4) {
+        const int len = n_bytes - 4;
+        const int per = (len + 63) / 64;
+        const int lo = min(lane * per, len), hi = min(lo + per, len);
+        uint32_t r = 0;
+        for (int i = lo; i < hi; i++) r = T[(r ^ bytes_l[i]) & 0xFF] ^ (r >> 8);
+        r = crc32_shift(r, unsigned(len - hi), zmat);
+        if (lane == 0) r ^= crc32_shift(0xFFFFFFFFu, unsigned(len), zmat);
+        for (int o = 32; o > 0; o >>= 1) r ^= __shfl_xor(r, o);
+        const uint32_t crc = ~r;
+        ok = 1;
+        for (int k = 0; k < 4; k++) if (bytes_l[len + k] != ((crc >> (8 * k)) & 0xFF)) ok = 0;
+    }
     if (lane == 0) {
         TbResult r{};
         r.user_bits = int(d.n_bits) - 32;
         r.avg_it = d.n_cw ? it_sum / int(d.n_cw) : 0;
-        int ok = 0;
-        if (n_bytes >= 4) {
-            const int len = n_bytes - 4;
-            uint32_t crc = 0xFFFFFFFFu;
-            int i = 0;
-            for (; i + 4 <= len; i += 4) {
-                crc ^= uint32_t(bytes_l[i]) | (uint32_t(bytes_l[i + 1]) << 8) | (uint32_t(bytes_l[i + 2]) << 16) | (uint32_t(bytes_l[i + 3]) << 24);
-                crc = T[3 * 256 + (crc & 0xFF)] ^ T[2 * 256 + ((crc >> 8) & 0xFF)] ^ T[256 + ((crc >> 16) & 0xFF)] ^ T[crc >> 24];
-            }
-            for (; i < len; i++) crc = T[(crc ^ bytes_l[i]) & 0xFF] ^ (crc >> 8);
-            crc = ~crc;
-            ok = 1;
-            for (int k = 0; k < 4; k++) if (bytes_l[len + k] != ((crc >> (8 * k)) & 0xFF)) ok = 0;
-        }
         r.crc_ok = ok;
         res[tb] = r;
     }
@@ -1051,9 +1063,35 @@ int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int
                     int stride, TbResult* res, int32_t* len, hipStream_t st)
 {
     if (n_tbs <= 0) return DTL_OK;
-    const size_t lds = 4096 + size_t((stride + 15) & ~15);
+    const size_t lds = (256 + 16 * 32) * 4 + size_t((stride + 15) & ~15);
     if (lds > 64 * 1024) { set_last_error("tb_check: transport block too large"); return DTL_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(tb_check_kernel, dim3(n_tbs), dim3(64), lds, st, tbs, n_tbs, bits, nit, staging, stride, res);
+    // zero-append maps of the CRC-32 register for 2^j bytes, j = 0..15 (built once per process and device)
+    static uint32_t* d_zmat = nullptr;
+    static int zmat_dev = -1;
+    int dev = 0;
+    DTL_HIP_CHECK(hipGetDevice(&dev));
+    if (!d_zmat || zmat_dev != dev) {
+        uint32_t T[256];
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+            T[i] = c;
+        }
+        std::vector<uint32_t> z(16 * 32);
+        for (int b = 0; b < 32; b++) { const uint32_t v = 1u << b; z[b] = T[v & 0xFF] ^ (v >> 8); } // one zero byte
+        for (int j = 1; j < 16; j++)
+            for (int b = 0; b < 32; b++) { // the map for 2^j bytes is the square of the one for 2^(j-1)
+                uint32_t v = z[(j - 1) * 32 + b], acc = 0;
+                for (int c = 0; c < 32; c++) if ((v >> c) & 1u) acc ^= z[(j - 1) * 32 + c];
+                z[j * 32 + b] = acc;
+            }
+        uint32_t* p = nullptr;
+        DTL_HIP_CHECK(hipMalloc(&p, z.size() * 4));
+        DTL_HIP_CHECK(hipMemcpy(p, z.data(), z.size() * 4, hipMemcpyHostToDevice));
+        d_zmat = p; zmat_dev = dev;
+    }
+    if ((stride / 1) >= (1 << 16)) { set_last_error("tb_check: transport block above 64 KiB"); return DTL_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(tb_check_kernel, dim3(n_tbs), dim3(64), lds, st, tbs, n_tbs, bits, nit, staging, stride, res, d_zmat);
     hipLaunchKernelGGL(tb_lengths_kernel, dim3((n_tbs + 255) / 256), dim3(256), 0, st, res, n_tbs, len);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;

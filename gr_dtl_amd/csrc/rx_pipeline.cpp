@@ -745,6 +745,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         ss.segs.push_back(sg);
     }
     const int n_segs = int(ss.segs.size());
+    lap("angle launch + segs");
     // ---- frame_detect_bb (optional): one work() buffer = the trigger stream produced by this call
     std::vector<int64_t> new_fixed;
     if (cfg.use_sync_correct) {
@@ -759,6 +760,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     } else {
         new_fixed = raw_triggers;
     }
+    lap("fix_sync");
     ss.trig_produced = produced;
     fixed_triggers = new_fixed;
     ss.pending_fixed.insert(ss.pending_fixed.end(), new_fixed.begin(), new_fixed.end());
@@ -782,8 +784,10 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         }
     }
     const int n_cand = int(cands.size());
+    lap("candidates");
     if (n_raw) {
         DTL_HIP_CHECK(hipStreamSynchronize(st));
+        lap("angle wait");
         std::memcpy(trigger_angles.data(), h_angle_.p, size_t(n_raw) * 4);
         // the phase a segment starts with is the previous segment's phase advanced to the new trigger
         // (before the first trigger the held angle is 0 and the phase stays 0)
@@ -795,13 +799,19 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
             if (first_new_seg + j > 0) {
                 const CfoSegment& pv = ss.segs[first_new_seg + j - 1];
                 double phase = pv.phase0 + double(sens * pv.angle) * double(sg.start - pv.start);
-                phase = std::fmod(phase + M_PI, 2.0 * M_PI);
+                // fmod(phase + pi, 2 pi): for the usual argument in [0, 4 pi) the remainder is the argument itself
+                // or one exact subtraction (Sterbenz), i.e. what fmod returns, without its division loop
+                const double x = phase + M_PI, two_pi = 2.0 * M_PI;
+                if (x >= 0.0 && x < two_pi) phase = x;
+                else if (x >= two_pi && x < 2.0 * two_pi) phase = x - two_pi;
+                else phase = std::fmod(x, two_pi);
                 if (phase < 0) phase += 2.0 * M_PI;
                 phase -= M_PI;
                 sg.phase0 = phase;
             }
         }
     }
+    lap("segment phases");
     stage_ms[1] = now_ms() - t0; t0 = now_ms();
 
     // ---- phases A and B, pipelined over chunks of candidates: the header kernel of every chunk is queued
