@@ -370,6 +370,7 @@ Receiver::~Receiver()
 {
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto& e : chunk_ev_) if (e) (void)hipEventDestroy(e);
+    if (ev_stats_) (void)hipEventDestroy(ev_stats_);
 }
 
 int Receiver::init()
@@ -943,6 +944,12 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     }
     if (!n_cand) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }
     if (payload_started && ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
+    if (fdesc.size()) { // per-frame SNR estimates travel back while the decoder runs
+        DTL_TRY(h_stats_.ensure(fdesc.size() * sizeof(FrameStat)));
+        DTL_HIP_CHECK(hipMemcpyAsync(h_stats_.p, d_stats_.p, fdesc.size() * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
+        if (!ev_stats_) DTL_HIP_CHECK(hipEventCreateWithFlags(&ev_stats_, hipEventDisableTiming));
+        DTL_HIP_CHECK(hipEventRecord(ev_stats_, st));
+    }
     ss.pending_fixed.erase(ss.pending_fixed.begin(), ss.pending_fixed.begin() + n_walked);
     const int n_frames = int(fdesc.size());
     n_payload_frames = n_frames;
@@ -1092,22 +1099,12 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         DTL_HIP_CHECK(hipMemcpyAsync(h_nofec_.p, d_nofec_info_.p, size_t(n_frames) * 8, hipMemcpyDeviceToHost, st));
         DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<uint8_t>() + 16, d_total_.p, 4, hipMemcpyDeviceToHost, st));
     }
+    // ---- per-frame sequential bookkeeping while the decoder is still running: lost frames (:124-138),
+    // feedback decision
     if (n_frames) {
-        DTL_TRY(h_stats_.ensure(size_t(n_frames) * sizeof(FrameStat)));
-        DTL_HIP_CHECK(hipMemcpyAsync(h_stats_.p, d_stats_.p, size_t(n_frames) * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
+        DTL_HIP_CHECK(hipEventSynchronize(ev_stats_));
+        std::memcpy(stats.data(), h_stats_.p, size_t(n_frames) * sizeof(FrameStat));
     }
-    DTL_HIP_CHECK(hipStreamSynchronize(st));
-    if (n_frames) std::memcpy(stats.data(), h_stats_.p, size_t(n_frames) * sizeof(FrameStat));
-    if (cfg.has_fec && n_tbs) std::memcpy(tb_res.data(), h_tbres_.p, size_t(n_tbs) * sizeof(TbResult));
-    if (!cfg.has_fec && n_frames) std::memcpy(nofec_info.data(), h_nofec_.p, size_t(n_frames) * 8);
-    total_bytes = *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 16);
-    stage_ms[6] = stage_ms[7] = 0.0;
-    if (ev_[0] && n_frames) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) stage_ms[7] = ms; }
-    if (ev_[2] && cfg.has_fec && n_tbs) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) stage_ms[6] = ms; }
-    n_payload_bytes = total_bytes;
-    stage_ms[4] = now_ms() - t0; t0 = now_ms();
-
-    // ---- per-frame sequential bookkeeping: lost frames (:124-138), feedback decision
     {
         if (!ss.fb_init) { ss.fb.init(cfg.mcs, cfg.hysteresis, cfg.decision_th, cfg.initial_mcs); ss.fb_init = true; }
         size_t fidx = 0;
@@ -1124,6 +1121,16 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
             fi.lost_frames = int(ss.lost_total);
         }
     }
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    if (cfg.has_fec && n_tbs) std::memcpy(tb_res.data(), h_tbres_.p, size_t(n_tbs) * sizeof(TbResult));
+    if (!cfg.has_fec && n_frames) std::memcpy(nofec_info.data(), h_nofec_.p, size_t(n_frames) * 8);
+    total_bytes = *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 16);
+    stage_ms[6] = stage_ms[7] = 0.0;
+    if (ev_[0] && n_frames) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) stage_ms[7] = ms; }
+    if (ev_[2] && cfg.has_fec && n_tbs) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) stage_ms[6] = ms; }
+    n_payload_bytes = total_bytes;
+    stage_ms[4] = now_ms() - t0; t0 = now_ms();
+
     // ---- TB records
     if (cfg.has_fec) {
         int64_t out_off = 0;

@@ -150,6 +150,7 @@ private:
         h_tbdesc_, h_stats_, h_tbres_, h_nofec_;
     DevBuf d_work_, d_carry_, d_llr_carry_;
     std::vector<hipEvent_t> chunk_ev_; // one per candidate chunk of the phase A/B pipeline
+    hipEvent_t ev_stats_ = nullptr;    // the per-frame SNR estimates have reached the host
 };
 
 } // namespace dtl
