@@ -86,8 +86,8 @@ int dtl_ldpc_decode_gather(const dtl_ldpc* h, const float* d_llr, const dtl_cw_d
  * (python/dtl/ofdm_adaptive_rx.py:32-59, python/dtl/ofdm_receiver.py:11-246): ofdm_sync_sc_cfb,
  * frame_detect_bb, delay/oscillator/mixer, header_payload_demux, fft_vcc, ofdm_chanest_vcvc,
  * header + payload frame equalisers, serializers, soft demapper, FEC decoder, fec_pack
- * (or the hard demapper + frame_pack of the no-FEC tail).  One call = one GR "work" over a
- * whole batch of frames; sample-stream state does not carry over between calls.
+ * (or the hard demapper + frame_pack of the no-FEC tail).  dtl_rx_process = one GR "work" over a
+ * self-contained batch of frames; dtl_rx_process_stream continues one sample stream over consecutive calls.
  * ------------------------------------------------------------------------------------------ */
 typedef struct dtl_rx dtl_rx;
 
