@@ -607,46 +607,86 @@ int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t s
     return process_stream(d_iq, n, flags, true, st);
 }
 
-int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st)
-{
-    StreamState& ss = *ss_;
-    struct ResetOnExit { // a failed or final call ends the stream
-        Receiver* r; bool armed;
-        ~ResetOnExit() { if (armed) r->reset_stream(); }
-    } reset_guard{ this, true };
-    if (n < 0 || (!d_iq && n > 0)) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
-    frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
-    n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
-    for (double& s : stage_ms) s = 0.0;
-    const int64_t W = ss.carry_len + n; // samples this call works on: carried tail + new ones
-    if (W == 0 || (n == 0 && !final)) { reset_guard.armed = final; return DTL_OK; } // nothing consumed, nothing produced
-    if (W > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
-    if (!uploaded_) DTL_TRY(upload_tables());
-    if (!ev_[0]) for (auto& e : ev_) DTL_HIP_CHECK(hipEventCreate(&e));
-    const int N = cfg.fft_len, cp = cfg.cp_len, P = N + cp, h = cfg.header_len(), L = cfg.frame_length;
-    const int hdr_syms = 2 + h;
-    const bool dbg = getenv("DTL_DEBUG") != nullptr;
-    double tdbg = now_ms();
-    auto lap = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "  [%s %.3f ms]\n", what, t - tdbg); tdbg = t; } };
-    double t0 = now_ms();
+// per-call context shared by the stages of process_stream (one GR work() call)
+struct Receiver::Call {
+    const cf32* d_iq = nullptr;     // caller's new samples
+    const cf32* iq = nullptr;       // working buffer: [carried tail | new samples]
+    int64_t n = 0, W = 0, A = 0, B = 0, E = 0; // new samples [B, E), working buffer [A, E), W = E - A
+    unsigned flags = 0;
+    bool final = false;
+    hipStream_t st = nullptr;
+    int N = 0, cp = 0, P = 0, h = 0, L = 0, hdr_syms = 0;
+    bool dbg = false;
+    double tdbg = 0, t0 = 0;
+    int64_t produced = 0;           // frame_detect_bb has been fed the trigger stream up to here
+    int n_raw = 0, n_segs = 0, n_cand = 0, n_frames = 0, n_tbs = 0, nofec_stride = 0;
+    std::vector<Candidate> cands;
+    std::vector<int64_t> cand_abs;
+    std::vector<FrameDesc> fdesc;
+    std::vector<uint32_t> llr_off;
+    uint64_t llr_total = 0;
+    std::vector<FrameStat> stats;
+    std::vector<int32_t> nofec_info;
+    std::vector<TbResult> tb_res;
+    uint32_t total_bytes = 0;
+    void lap(const char* what)
+    {
+        if (!dbg) return;
+        const double t = now_ms();
+        fprintf(stderr, "  [%s %.3f ms]\n", what, t - tdbg);
+        tdbg = t;
+    }
+};
 
+// the stages were written as one function; they keep its local names through these aliases
+#define RX_CALL_LOCALS(c)                                                                                       \
+    StreamState& ss = *ss_;                                                                                     \
+    [[maybe_unused]] const cf32* const iq = (c).iq;                                                             \
+    [[maybe_unused]] const int64_t n = (c).n, W = (c).W, A = (c).A, B = (c).B, E = (c).E;                       \
+    [[maybe_unused]] const unsigned flags = (c).flags;                                                          \
+    [[maybe_unused]] const bool final = (c).final, dbg = (c).dbg;                                               \
+    [[maybe_unused]] hipStream_t const st = (c).st;                                                             \
+    [[maybe_unused]] const int N = (c).N, cp = (c).cp, P = (c).P, h = (c).h, L = (c).L, hdr_syms = (c).hdr_syms; \
+    [[maybe_unused]] double& t0 = (c).t0;                                                                       \
+    [[maybe_unused]] int64_t& produced = (c).produced;                                                          \
+    [[maybe_unused]] int &n_raw = (c).n_raw, &n_segs = (c).n_segs, &n_cand = (c).n_cand, &n_frames = (c).n_frames, \
+        &n_tbs = (c).n_tbs, &nofec_stride = (c).nofec_stride;                                                   \
+    [[maybe_unused]] auto& cands = (c).cands;                                                                   \
+    [[maybe_unused]] auto& cand_abs = (c).cand_abs;                                                             \
+    [[maybe_unused]] auto& fdesc = (c).fdesc;                                                                   \
+    [[maybe_unused]] auto& llr_off = (c).llr_off;                                                               \
+    [[maybe_unused]] uint64_t& llr_total = (c).llr_total;                                                       \
+    [[maybe_unused]] auto& stats = (c).stats;                                                                   \
+    [[maybe_unused]] auto& nofec_info = (c).nofec_info;                                                         \
+    [[maybe_unused]] auto& tb_res = (c).tb_res;                                                                 \
+    [[maybe_unused]] uint32_t& total_bytes = (c).total_bytes;                                                   \
+    [[maybe_unused]] auto lap = [&](const char* what) { (c).lap(what); }
+
+// working buffer of one call
+int Receiver::stream_begin(Call& c)
+{
+    RX_CALL_LOCALS(c);
     // ---- working buffer: [carried tail | new samples]; A = absolute index of its first sample (a
     // multiple of the sync kernel's tile, so that every metric value is computed exactly as in one batch)
-    const int64_t A = ss.carry_len ? ss.carry_abs : ss.next_abs;
-    const int64_t B = ss.next_abs, E = B + n; // new samples are [B, E)
-    const cf32* iq = d_iq;
     if (ss.carry_len) {
         DTL_TRY(d_work_.ensure(size_t(W) * sizeof(cf32)));
         DTL_HIP_CHECK(hipMemcpyAsync(d_work_.p, d_carry_.p, size_t(ss.carry_len) * sizeof(cf32), hipMemcpyDeviceToDevice, st));
-        if (n) DTL_HIP_CHECK(hipMemcpyAsync(d_work_.as<cf32>() + ss.carry_len, d_iq, size_t(n) * sizeof(cf32), hipMemcpyDeviceToDevice, st));
-        iq = d_work_.as<cf32>();
+        if (n) DTL_HIP_CHECK(hipMemcpyAsync(d_work_.as<cf32>() + ss.carry_len, c.d_iq, size_t(n) * sizeof(cf32), hipMemcpyDeviceToDevice, st));
+        c.iq = d_work_.as<cf32>();
     }
     lap("work buffer");
 
+    return DTL_OK;
+}
+
+// K1: Schmidl-Cox metric, threshold crossings, plateau detector
+int Receiver::stage_sync(Call& c)
+{
+    RX_CALL_LOCALS(c);
     // ---- K1: timing metric -> threshold crossings -> plateau detector (host), pipelined over up to four
     // sample ranges: the crossings of one range are sorted and run through the (incremental) plateau
     // detector while the sync kernel works on the next range.
-    int64_t produced = E;
+    produced = E;
     double plateau_ms = 0.0;
     unsigned n_edges_total = 0;
     {
@@ -724,8 +764,15 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     stage_ms[0] = now_ms() - t0; t0 = now_ms();
     dbg_plateau_ms = plateau_ms;
 
+    return DTL_OK;
+}
+
+// K1b + frame_detect_bb + candidate list
+int Receiver::stage_triggers(Call& c)
+{
+    RX_CALL_LOCALS(c);
     // ---- K1b: arg(P) at the raw triggers; oscillator segments (sample_and_hold + frequency_modulator_fc)
-    const int n_raw = int(raw_triggers.size());
+    n_raw = int(raw_triggers.size());
     trigger_angles.assign(n_raw, 0.0f);
     if (n_raw) {
         std::vector<int64_t> rel(raw_triggers);
@@ -745,7 +792,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         sg.start = raw_triggers[j];
         ss.segs.push_back(sg);
     }
-    const int n_segs = int(ss.segs.size());
+    n_segs = int(ss.segs.size());
     lap("angle launch + segs");
     // ---- frame_detect_bb (optional): one work() buffer = the trigger stream produced by this call
     std::vector<int64_t> new_fixed;
@@ -767,8 +814,8 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     ss.pending_fixed.insert(ss.pending_fixed.end(), new_fixed.begin(), new_fixed.end());
     // candidates for phase A: every pending trigger whose samples are here (a continued stream waits
     // for the whole frame, the end of a stream only needs the header symbols)
-    std::vector<Candidate> cands;
-    std::vector<int64_t> cand_abs;
+    cands.clear();
+    cand_abs.clear();
     cands.reserve(ss.pending_fixed.size());
     cand_abs.reserve(ss.pending_fixed.size());
     {
@@ -784,7 +831,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
             cand_abs.push_back(tpos);
         }
     }
-    const int n_cand = int(cands.size());
+    n_cand = int(cands.size());
     lap("candidates");
     if (n_raw) {
         DTL_HIP_CHECK(hipStreamSynchronize(st));
@@ -815,23 +862,30 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     lap("segment phases");
     stage_ms[1] = now_ms() - t0; t0 = now_ms();
 
+    return DTL_OK;
+}
+
+// phase A (headers, demux walk) and phase B (payload kernels)
+int Receiver::stage_frames(Call& c)
+{
+    RX_CALL_LOCALS(c);
     // ---- phases A and B, pipelined over chunks of candidates: the header kernel of every chunk is queued
     // at once; while the GPU works through them the host takes chunk after chunk of header records
     // (header_payload_demux walk + header_parser state, both sequential) and queues that chunk's payload
     // kernel behind them.  Only the walk of the last chunk is not hidden behind GPU work.
     std::vector<HeaderRec> recs(n_cand);
-    std::vector<FrameDesc> fdesc;
-    std::vector<uint32_t> llr_off;
+    fdesc.clear();
+    llr_off.clear();
     fdesc.reserve(n_cand);
     llr_off.reserve(n_cand);
     frames.reserve(n_cand);
     const int n_chunks = n_cand >= 8192 ? 4 : 1;
     const int max_bps = 4;
-    const int nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
+    nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
     cf32 *eh = nullptr, *es = nullptr, *ss_out = nullptr;
     uint8_t* nofec_bytes = nullptr;
     int32_t* nofec_inf = nullptr;
-    uint64_t llr_total = uint64_t(ss.llr_carry_len);
+    llr_total = uint64_t(ss.llr_carry_len);
     if (n_cand) {
         std::vector<CfoSegment> segs_rel(ss.segs);
         for (auto& sg : segs_rel) sg.start -= A;
@@ -951,16 +1005,23 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         DTL_HIP_CHECK(hipEventRecord(ev_stats_, st));
     }
     ss.pending_fixed.erase(ss.pending_fixed.begin(), ss.pending_fixed.begin() + n_walked);
-    const int n_frames = int(fdesc.size());
+    n_frames = int(fdesc.size());
     n_payload_frames = n_frames;
     n_llr = int64_t(llr_total);
-    std::vector<FrameStat> stats(n_frames);
-    std::vector<int32_t> nofec_info(size_t(n_frames) * 2, 0);
-    uint32_t total_bytes = 0;
+    stats.assign(size_t(n_frames), FrameStat{});
+    nofec_info.assign(size_t(n_frames) * 2, 0);
+    total_bytes = 0;
     if (!n_cand && ss.llr_carry_len) { // nothing new, but a transport block is still waiting for its frames
         DTL_TRY(d_llr.ensure((size_t(llr_total) + 4096) * 4));
         DTL_HIP_CHECK(hipMemcpyAsync(d_llr.p, d_llr_carry_.p, size_t(ss.llr_carry_len) * 4, hipMemcpyDeviceToDevice, st));
     }
+    return DTL_OK;
+}
+
+// transport blocks: reassembly tables, LDPC, CRC, compaction; per-frame bookkeeping
+int Receiver::stage_blocks(Call& c)
+{
+    RX_CALL_LOCALS(c);
     TbAssembler& asmb = ss.asmb;
     asmb.done.clear();
     if (cfg.has_fec) {
@@ -1024,7 +1085,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     }
     if (asmb.overflow) { set_last_error("transport block spread over more than 4 stream segments"); return DTL_ERR_UNSUPPORTED; }
     // global codeword order: grouped per LDPC code, TB order inside a group
-    const int n_tbs = int(asmb.done.size());
+    n_tbs = int(asmb.done.size());
     std::vector<TbGather> gathers(n_tbs);
     std::vector<TbDesc> tb_desc(n_tbs);
     std::vector<std::pair<int, std::pair<size_t, size_t>>> code_ranges; // code -> [first, count)
@@ -1060,7 +1121,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     stage_ms[3] = now_ms() - t0; t0 = now_ms();
 
     // ---- LDPC -> TB check -> compaction (the payload kernel is already running)
-    std::vector<TbResult> tb_res(n_tbs);
+    tb_res.assign(size_t(n_tbs), TbResult{});
     *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 16) = 0; // total bytes (filled by an async D2H below)
     DTL_TRY(d_total_.ensure(16));
     if (cfg.has_fec) {
@@ -1131,6 +1192,14 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     n_payload_bytes = total_bytes;
     stage_ms[4] = now_ms() - t0; t0 = now_ms();
 
+    return DTL_OK;
+}
+
+// per-block records of the result
+int Receiver::stage_records(Call& c)
+{
+    RX_CALL_LOCALS(c);
+    TbAssembler& asmb = ss.asmb;
     // ---- TB records
     if (cfg.has_fec) {
         int64_t out_off = 0;
@@ -1159,7 +1228,14 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     }
     stage_ms[5] = now_ms() - t0;
     if (dbg) fprintf(stderr, "  [n_edges=%u plateau %.3f ms]\n", dbg_n_edges, dbg_plateau_ms);
-    if (final) return DTL_OK; // reset_guard ends the stream
+    return DTL_OK;
+}
+
+// what the next call needs from this one
+int Receiver::stream_end(Call& c)
+{
+    RX_CALL_LOCALS(c);
+    TbAssembler& asmb = ss.asmb;
 
     // ---- what the next call needs from this one
     // (a) soft bits of the transport block still being received, compacted into d_llr_carry_
@@ -1214,6 +1290,43 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     }
     DTL_HIP_CHECK(hipStreamSynchronize(st)); // the caller may reuse its buffer; d_work_ is reused by the next call
     ss.next_abs = E;
+    return DTL_OK;
+}
+
+int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st)
+{
+    StreamState& ss = *ss_;
+    struct ResetOnExit { // a failed or final call ends the stream
+        Receiver* r; bool armed;
+        ~ResetOnExit() { if (armed) r->reset_stream(); }
+    } reset_guard{ this, true };
+    if (n < 0 || (!d_iq && n > 0)) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
+    frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
+    n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
+    for (double& s : stage_ms) s = 0.0;
+    const int64_t W = ss.carry_len + n; // samples this call works on: carried tail + new ones
+    if (W == 0 || (n == 0 && !final)) { reset_guard.armed = final; return DTL_OK; } // nothing consumed, nothing produced
+    if (W > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
+    if (!uploaded_) DTL_TRY(upload_tables());
+    if (!ev_[0]) for (auto& e : ev_) DTL_HIP_CHECK(hipEventCreate(&e));
+    Call c;
+    c.d_iq = d_iq; c.iq = d_iq; c.n = n; c.W = W; c.flags = flags; c.final = final; c.st = st;
+    // A = absolute index of the working buffer's first sample (a multiple of the sync kernel's tile, so that
+    // every metric value is computed exactly as in one batch); new samples are [B, E)
+    c.A = ss.carry_len ? ss.carry_abs : ss.next_abs;
+    c.B = ss.next_abs; c.E = c.B + n;
+    c.N = cfg.fft_len; c.cp = cfg.cp_len; c.P = c.N + c.cp; c.h = cfg.header_len(); c.L = cfg.frame_length;
+    c.hdr_syms = 2 + c.h;
+    c.dbg = getenv("DTL_DEBUG") != nullptr;
+    c.tdbg = c.t0 = now_ms();
+    DTL_TRY(stream_begin(c));
+    DTL_TRY(stage_sync(c));
+    DTL_TRY(stage_triggers(c));
+    DTL_TRY(stage_frames(c));
+    DTL_TRY(stage_blocks(c));
+    DTL_TRY(stage_records(c));
+    if (final) return DTL_OK; // reset_guard ends the stream
+    DTL_TRY(stream_end(c));
     reset_guard.armed = false;
     return DTL_OK;
 }

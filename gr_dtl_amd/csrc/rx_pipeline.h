@@ -136,7 +136,15 @@ public:
 
 private:
     struct StreamState;
+    struct Call;
     std::unique_ptr<StreamState> ss_;
+    int stream_begin(Call& c);
+    int stage_sync(Call& c);
+    int stage_triggers(Call& c);
+    int stage_frames(Call& c);
+    int stage_blocks(Call& c);
+    int stage_records(Call& c);
+    int stream_end(Call& c);
     int upload_tables();
     RxTables tab_{};
     DevBuf tab_blob_;
