@@ -170,6 +170,9 @@ typedef struct dtl_rx_result {
     int32_t frame_capacity, hdr_bits, frame_samples, pad;
 } dtl_rx_result;
 
+/* Threading: one handle serves one call at a time (it owns its device buffers, staging memory and stream
+ * state); different handles may run concurrently from different host threads on different HIP streams
+ * (bench.py --in-flight 2 does that to overlap one batch's host phases with another's decoder kernels). */
 int dtl_rx_create(const dtl_rx_cfg* cfg, dtl_rx** out);
 void dtl_rx_destroy(dtl_rx* h);
 /* d_iq: n_samples complex64 (re,im) on the device */
