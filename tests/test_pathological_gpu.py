@@ -1,0 +1,54 @@
+"""Inputs no transmitter produces: the receive path must neither fault nor hang, stay consistent with the oracle on
+the integer outputs where the oracle is defined, and stay usable afterwards.  (A kernel fault on the GPU box can
+take the node down, so every case is small.)"""
+import numpy as np
+import pytest
+
+from helpers import make_pair, make_stream
+
+
+def _cases(rng, frame):
+    n = 30000
+    t = np.arange(n)
+    yield "zeros", np.zeros(n, np.complex64)
+    yield "dc", np.full(n, 0.5 + 0.25j, np.complex64)                       # metric == 1 everywhere: one endless plateau
+    yield "tone", np.exp(2j * np.pi * 0.03125 * t).astype(np.complex64)     # periodic with N/2: endless plateau too
+    yield "huge", (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(1e18)
+    yield "tiny", (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(1e-30)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    x[1000:1010] = np.nan
+    x[5000] = np.inf
+    yield "nan_inf", x
+    yield "frame_repeated", np.tile(frame[:2000], 15).astype(np.complex64)  # preambles at a wrong spacing
+    yield "one_sample", np.ones(1, np.complex64)
+    yield "shorter_than_fft", np.ones(63, np.complex64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sync_correct", [True, False])
+def test_pathological_streams(oracle, dtl, cuda, sync_correct):
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, use_sync_correct=sync_correct)
+    user, hdrs, good = make_stream(oracle, ocfg, code, 2, 3000, 16.0, seed=8)
+    rx = dtl.ofdm_receiver(pcfg)
+    want = rx.work(torch.from_numpy(good).to(cuda)).payload.cpu().numpy()
+    assert want.size > 2000
+    rng = np.random.default_rng(12)
+    for name, x in _cases(rng, good[100:]):
+        xt = torch.from_numpy(x).to(cuda)
+        res = rx.work(xt)                       # must return (errors are allowed to be reported, not to crash)
+        assert res.payload.numel() == res.n_payload_bytes, name
+        if name not in ("nan_inf", "huge"):     # the oracle's float compares on NaN / overflow are not pinned
+            ref = oracle.rx_stream(ocfg, code, x, want=("frames", "trig"))
+            np.testing.assert_array_equal(res.raw_triggers, np.nonzero(ref["trig_raw"])[0], err_msg=name)
+            assert len(res.frames) == ref["n_frames"], name
+        # the same input through the streaming entry point in odd slices
+        rx.reset()
+        got = 0
+        for lo in range(0, max(x.size, 1), 7001):
+            r = rx.feed(xt[lo:lo + 7001], final=(lo + 7001 >= x.size))
+            got += r.n_payload_bytes
+        assert got == res.n_payload_bytes or sync_correct, name
+        # ... and the receiver still decodes a good stream afterwards
+        again = rx.work(torch.from_numpy(good).to(cuda)).payload.cpu().numpy()
+        np.testing.assert_array_equal(again, want, err_msg=name)
