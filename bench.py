@@ -145,14 +145,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal switches for a one-GPU box (the real multi-GPU run uses neither): every rank on device 0 with the
+    # gloo backend exercises the multi-process path; DTL_BENCH_FORCE_DIST initialises RCCL with a single rank
+    rehearsal = os.environ.get("DTL_BENCH_REHEARSAL_GLOO") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
-    force_dist = os.environ.get("DTL_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path with one rank
+    force_dist = os.environ.get("DTL_BENCH_FORCE_DIST") == "1"
     if world > 1 or (force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
 
     w = WORKLOADS[args.workload]
     n_frames_req = args.frames or w["frames"]
@@ -215,7 +222,7 @@ def main():
     from gr_dtl_amd.sharding import combine
     # max-over-ranks time, summed counters (two tiny all-reduces; no data-path collective)
     elapsed, tot = combine(elapsed, [n_samples, res.n_payload_bytes, res.n_payload_frames, res.n_codewords],
-                           dist, device)
+                           dist, None if rehearsal else device)
     total_samples = float(tot[0])
     ms_per_step = elapsed / args.steps * 1e3
     value = total_samples * args.steps / elapsed / 1e6
