@@ -3,8 +3,9 @@
 // The receive chain's soft outputs feed an iterative decoder whose non-converging codewords amplify
 // last-bit differences; libm-style "<= 1 ulp, unspecified bits" functions (or v_exp_f32/v_log_f32)
 // would make the soft bits irreproducible against a CPU run.  These routines use only IEEE single
-// operations in a fixed order (Cody-Waite reduction, fdlibm-class polynomials, no FMA contraction --
-// the including file sets `#pragma clang fp contract(off)`), so a CPU that executes the same sequence
+// operations in a fixed order (Cody-Waite reduction, fdlibm-class polynomials in Horner form with the
+// fused multiply-adds written out; nothing is left to contraction -- the including file sets
+// `#pragma clang fp contract(off)`), so a CPU that executes the same sequence
 // (the test oracle does) obtains bit-identical results.  Accuracy <= 2 ulp.
 #pragma once
 
@@ -19,16 +20,16 @@ __device__ __forceinline__ float dm_exp(float x)
 {
     const float kf = rintf(x * 1.44269504f);
     const int k = int(kf);
-    float r = x - kf * 0.693145752f;
-    r = r - kf * 1.42860677e-06f;
+    float r = __builtin_fmaf(-kf, 0.693145752f, x);
+    r = __builtin_fmaf(-kf, 1.42860677e-06f, r);
     float p = 1.9841270e-4f;
-    p = p * r + 1.3888889e-3f;
-    p = p * r + 8.3333338e-3f;
-    p = p * r + 4.1666668e-2f;
-    p = p * r + 1.6666667e-1f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = __builtin_fmaf(p, r, 1.3888889e-3f);
+    p = __builtin_fmaf(p, r, 8.3333338e-3f);
+    p = __builtin_fmaf(p, r, 4.1666668e-2f);
+    p = __builtin_fmaf(p, r, 1.6666667e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
     // p * 2^k with a single rounding (v_ldexp_f32); bit-identical to the CPU oracle's two-step
     // (p * 2^(k/2)) * 2^(k - k/2), whose first product is exact (tools/math_check.hip: all 2^32 inputs)
     float res = ldexpf(p, k);
@@ -68,10 +69,10 @@ __device__ __forceinline__ float dm_log(float x0)
     const float f = m - 1.0f;
     const float s = dm_div_inrange(f, 2.0f + f);
     const float z = s * s;
-    const float R = z * (0.66666662693f + z * (0.40000972152f + z * (0.28498786688f + z * 0.24279078841f)));
+    const float R = z * __builtin_fmaf(z, __builtin_fmaf(z, __builtin_fmaf(z, 0.24279078841f, 0.28498786688f), 0.40000972152f), 0.66666662693f);
     const float hfsq = 0.5f * f * f;
     const float ef = float(e);
-    float res = ef * 6.9313812256e-01f + (f - (hfsq - (s * (hfsq + R) + ef * 9.0580006145e-06f)));
+    float res = __builtin_fmaf(ef, 6.9313812256e-01f, f - (hfsq - __builtin_fmaf(s, hfsq + R, ef * 9.0580006145e-06f)));
     res = (x0 == __int_as_float(0x7f800000)) ? x0 : res;
     res = (x0 == 0.0f) ? __int_as_float(0xff800000) : res;
     res = (x0 < 0.0f) ? __int_as_float(0x7fc00000) : res;
@@ -92,11 +93,13 @@ __device__ __forceinline__ void dm_sincos(float x, float* sn, float* cs)
     const float xr = float(xd);
     const float qf = rintf(xr * 0.636619772f);
     const int q = int(qf);
-    float r = xr - qf * 1.57079601e+00f;
-    r = r - qf * 3.13916473e-07f;
+    float r = __builtin_fmaf(-qf, 1.57079601e+00f, xr);
+    r = __builtin_fmaf(-qf, 3.13916473e-07f, r);
     const float z = r * r;
-    const float sp = r + r * z * (-1.6666667163e-01f + z * (8.3333337680e-03f + z * (-1.9841270114e-04f + z * 2.7557314297e-06f)));
-    const float cp = 1.0f - 0.5f * z + z * z * (4.1666667908e-02f + z * (-1.3888889225e-03f + z * (2.4801587642e-05f + z * -2.7557314297e-07f)));
+    const float ps = __builtin_fmaf(z, __builtin_fmaf(z, __builtin_fmaf(z, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+    const float sp = __builtin_fmaf(r * z, ps, r);
+    const float pc = __builtin_fmaf(z, __builtin_fmaf(z, __builtin_fmaf(z, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+    const float cp = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
     switch (q & 3) {
     case 0: *sn = sp; *cs = cp; break;
     case 1: *sn = cp; *cs = -sp; break;

@@ -1,6 +1,7 @@
 /*
  * orc_math.h -- ORACLE (test infrastructure): float expf / logf / sincosf with a FIXED, documented
- * operation sequence (IEEE single ops only, no FMA contraction), <= 2 ulp from the true value.
+ * operation sequence (IEEE single operations, fused multiply-adds written out explicitly, nothing left to
+ * the compiler's contraction), <= 2 ulp from the true value.
  *
  * Why: the reference calls libm (expf/logf in constellation::calc_soft_dec, sincosf in gr_expj and
  * the oscillator); libm results differ between platforms in the last bit, and the LDPC decoder of a
@@ -18,6 +19,7 @@
 
 static inline float orc_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t orc_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+#define ORC_FMA(a, b, c) __builtin_fmaf((a), (b), (c)) /* one rounding; vfmadd on x86-64-v3, v_fma_f32 on the GPU */
 
 /* exp(x): k = rint(x*log2e); r = x - k*ln2 (hi/lo); degree-7 polynomial; two-step scaling by 2^k */
 static inline float orc_expf(float x)
@@ -27,16 +29,16 @@ static inline float orc_expf(float x)
     if (x < -103.97208f) return 0.0f;
     float kf = rintf(x * 1.44269504f);
     int k = (int)kf;
-    float r = x - kf * 0.693145752f;
-    r = r - kf * 1.42860677e-06f;
+    float r = ORC_FMA(-kf, 0.693145752f, x);
+    r = ORC_FMA(-kf, 1.42860677e-06f, r);
     float p = 1.9841270e-4f;
-    p = p * r + 1.3888889e-3f;
-    p = p * r + 8.3333338e-3f;
-    p = p * r + 4.1666668e-2f;
-    p = p * r + 1.6666667e-1f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = ORC_FMA(p, r, 1.3888889e-3f);
+    p = ORC_FMA(p, r, 8.3333338e-3f);
+    p = ORC_FMA(p, r, 4.1666668e-2f);
+    p = ORC_FMA(p, r, 1.6666667e-1f);
+    p = ORC_FMA(p, r, 0.5f);
+    p = ORC_FMA(p, r, 1.0f);
+    p = ORC_FMA(p, r, 1.0f);
     int k1 = k / 2, k2 = k - k1; /* |k1|,|k2| <= 75: both scale factors are normal numbers */
     float s1 = orc_bits2f((uint32_t)(k1 + 127) << 23), s2 = orc_bits2f((uint32_t)(k2 + 127) << 23);
     return (p * s1) * s2;
@@ -59,10 +61,10 @@ static inline float orc_logf(float x)
     float f = m - 1.0f;
     float s = f / (2.0f + f);
     float z = s * s;
-    float R = z * (0.66666662693f + z * (0.40000972152f + z * (0.28498786688f + z * 0.24279078841f)));
+    float R = z * ORC_FMA(z, ORC_FMA(z, ORC_FMA(z, 0.24279078841f, 0.28498786688f), 0.40000972152f), 0.66666662693f);
     float hfsq = 0.5f * f * f;
     float ef = (float)e;
-    return ef * 6.9313812256e-01f + (f - (hfsq - (s * (hfsq + R) + ef * 9.0580006145e-06f)));
+    return ORC_FMA(ef, 6.9313812256e-01f, f - (hfsq - ORC_FMA(s, hfsq + R, ef * 9.0580006145e-06f)));
 }
 
 /* sin and cos of x, any finite x: reduction to [-pi, pi) in double, quadrant split, fdlibm kernels */
@@ -77,11 +79,13 @@ static inline void orc_sincosf(float x, float* sn, float* cs)
     float xr = (float)xd;
     float qf = rintf(xr * 0.636619772f); /* 2/pi */
     int q = (int)qf;
-    float r = xr - qf * 1.57079601e+00f;  /* pi/2 hi */
-    r = r - qf * 3.13916473e-07f;         /* pi/2 lo */
+    float r = ORC_FMA(-qf, 1.57079601e+00f, xr);  /* pi/2 hi */
+    r = ORC_FMA(-qf, 3.13916473e-07f, r);         /* pi/2 lo */
     float z = r * r;
-    float sp = r + r * z * (-1.6666667163e-01f + z * (8.3333337680e-03f + z * (-1.9841270114e-04f + z * 2.7557314297e-06f)));
-    float cp = 1.0f - 0.5f * z + z * z * (4.1666667908e-02f + z * (-1.3888889225e-03f + z * (2.4801587642e-05f + z * -2.7557314297e-07f)));
+    float ps = ORC_FMA(z, ORC_FMA(z, ORC_FMA(z, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+    float sp = ORC_FMA(r * z, ps, r);
+    float pc = ORC_FMA(z, ORC_FMA(z, ORC_FMA(z, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+    float cp = ORC_FMA(z * z, pc, ORC_FMA(-0.5f, z, 1.0f));
     switch (q & 3) {
     case 0: *sn = sp; *cs = cp; break;
     case 1: *sn = cp; *cs = -sp; break;

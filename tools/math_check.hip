@@ -17,16 +17,16 @@ __device__ __forceinline__ float exp_two_step(float x)
     if (x < -103.97208f) return 0.0f;
     const float kf = rintf(x * 1.44269504f);
     const int k = int(kf);
-    float r = x - kf * 0.693145752f;
-    r = r - kf * 1.42860677e-06f;
+    float r = __builtin_fmaf(-kf, 0.693145752f, x);
+    r = __builtin_fmaf(-kf, 1.42860677e-06f, r);
     float p = 1.9841270e-4f;
-    p = p * r + 1.3888889e-3f;
-    p = p * r + 8.3333338e-3f;
-    p = p * r + 4.1666668e-2f;
-    p = p * r + 1.6666667e-1f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = __builtin_fmaf(p, r, 1.3888889e-3f);
+    p = __builtin_fmaf(p, r, 8.3333338e-3f);
+    p = __builtin_fmaf(p, r, 4.1666668e-2f);
+    p = __builtin_fmaf(p, r, 1.6666667e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
     const int k1 = k / 2, k2 = k - k1;
     const float s1 = __int_as_float((k1 + 127) << 23), s2 = __int_as_float((k2 + 127) << 23);
     return (p * s1) * s2;
@@ -49,10 +49,10 @@ __device__ float log_plain(float x)
     const float f = m - 1.0f;
     const float s = f / (2.0f + f);
     const float z = s * s;
-    const float R = z * (0.66666662693f + z * (0.40000972152f + z * (0.28498786688f + z * 0.24279078841f)));
+    const float R = z * __builtin_fmaf(z, __builtin_fmaf(z, __builtin_fmaf(z, 0.24279078841f, 0.28498786688f), 0.40000972152f), 0.66666662693f);
     const float hfsq = 0.5f * f * f;
     const float ef = float(e);
-    return ef * 6.9313812256e-01f + (f - (hfsq - (s * (hfsq + R) + ef * 9.0580006145e-06f)));
+    return __builtin_fmaf(ef, 6.9313812256e-01f, f - (hfsq - __builtin_fmaf(s, hfsq + R, ef * 9.0580006145e-06f)));
 }
 
 __global__ void check_log(unsigned long long* mism, unsigned* example)
