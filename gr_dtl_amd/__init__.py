@@ -11,3 +11,4 @@ from .ofdm_adaptive_config import (constellation_type_t, get_bits_per_symbol, ma
 from .ofdm_receiver import ofdm_adaptive_rx, ofdm_receiver  # noqa: F401
 from .frame_file_store import ber_report, frame_file_store, read_frames, store_rx_frames, store_tx_frames  # noqa: F401
 from .monitor import monitor_probe  # noqa: F401
+from .ofdm_transmitter import ofdm_adaptive_tx, ofdm_transmitter  # noqa: F401

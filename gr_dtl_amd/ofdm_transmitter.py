@@ -362,3 +362,6 @@ class ofdm_adaptive_tx:
 
     def work(self, user_bytes, constellation, fec_scheme=None, first_frame_no=0, first_tb_no=0):
         return self.direct_tx.work(user_bytes, constellation, fec_scheme, first_frame_no, first_tb_no)
+
+    def work_device(self, user, constellation, fec_scheme=None, **kwargs):
+        return self.direct_tx.work_device(user, constellation, fec_scheme, **kwargs)
