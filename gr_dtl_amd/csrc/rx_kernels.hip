@@ -24,6 +24,11 @@ __device__ __forceinline__ cf32 cmul(cf32 a, cf32 b)
 {
     return { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re };
 }
+// twiddle product of the FFT butterflies: one fused multiply-add per component (the oracle's FFT does the same)
+__device__ __forceinline__ cf32 cmul_tw(cf32 a, cf32 w)
+{
+    return { __builtin_fmaf(a.re, w.re, -(a.im * w.im)), __builtin_fmaf(a.re, w.im, a.im * w.re) };
+}
 __device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return { a.re + b.re, a.im + b.im }; }
 __device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return { a.re - b.re, a.im - b.im }; }
 __device__ __forceinline__ cf32 cscale(float s, cf32 a) { return { s * a.re, s * a.im }; }
@@ -136,15 +141,15 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
             // stage st: (i0,i1) and (i2,i3), twiddle W^(k N / 2h)
             const cf32 w0 = tw[k << (logN - st - 1)];
             cf32 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
-            cf32 v = cmul(a1, w0);
+            cf32 v = cmul_tw(a1, w0);
             a1 = csub(a0, v); a0 = cadd(a0, v);
-            v = cmul(a3, w0);
+            v = cmul_tw(a3, w0);
             a3 = csub(a2, v); a2 = cadd(a2, v);
             // stage st+1: (i0,i2) with W^(k N / 4h), (i1,i3) with W^((k+h) N / 4h)
             const cf32 w1 = tw[k << (logN - st - 2)], w2 = tw[(k + h) << (logN - st - 2)];
-            v = cmul(a2, w1);
+            v = cmul_tw(a2, w1);
             a2 = csub(a0, v); a0 = cadd(a0, v);
-            v = cmul(a3, w2);
+            v = cmul_tw(a3, w2);
             a3 = csub(a1, v); a1 = cadd(a1, v);
             x[i0] = a0; x[i1] = a1; x[i2] = a2; x[i3] = a3;
         }
@@ -159,7 +164,7 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
                 const int a = (grp << (st + 1)) + k, b = a + half;
                 const cf32 w = tw[k << (logN - st - 1)];
                 const cf32 uu = x[a];
-                const cf32 vv = cmul(x[b], w);
+                const cf32 vv = cmul_tw(x[b], w);
                 x[a] = cadd(uu, vv);
                 x[b] = csub(uu, vv);
             }

@@ -19,7 +19,11 @@ struct TxCodeSet {
     TxCodeTables c[8];
 };
 
-__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { return { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re }; }
+// twiddle product: one fused multiply-add per component, as in the receive kernels and the oracle's FFT
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 w)
+{
+    return { __builtin_fmaf(a.re, w.re, -(a.im * w.im)), __builtin_fmaf(a.re, w.im, a.im * w.re) };
+}
 
 // ------------------------------------------------------------------------------------------
 // ofdm_adaptive_fec_frame_bvb_impl.cc:397-408 (user bytes + CRC-32, unpacked LSB first),

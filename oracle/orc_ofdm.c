@@ -57,8 +57,9 @@ static void fft_inplace(cf* x, int n, int sign)
                 cf w = (float)cos(ang) + (float)sin(ang) * I;
                 cf u = x[i + k];
                 cf a = x[i + k + len / 2];
-                cf v = (crealf(a) * crealf(w) - cimagf(a) * cimagf(w)) +
-                       (crealf(a) * cimagf(w) + cimagf(a) * crealf(w)) * I;
+                /* twiddle product with one fused multiply-add per component (the kernels do the same) */
+                cf v = __builtin_fmaf(crealf(a), crealf(w), -(cimagf(a) * cimagf(w))) +
+                       __builtin_fmaf(crealf(a), cimagf(w), cimagf(a) * crealf(w)) * I;
                 x[i + k] = u + v;
                 x[i + k + len / 2] = u - v;
             }
