@@ -3,6 +3,7 @@
 
 #include "dtl_common.h"
 #include "ldpc_bp.h"
+#include "rx_kernels.h"
 #include "rx_pipeline.h"
 #include "tx_pipeline.h"
 
@@ -272,6 +273,82 @@ int dtl_rx_process_stream(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flag
 void dtl_rx_reset(dtl_rx* h) { if (h) h->rx.reset_stream(); }
 
 int64_t dtl_rx_stream_position(const dtl_rx* h) { return h ? h->rx.stream_position() : 0; }
+
+int dtl_sync_sc(const float* d_iq, int64_t n, int32_t fft_len, int32_t cp_len, float threshold, float* d_metric,
+                int64_t* triggers_host, float* angles_host, int64_t cap, int64_t* n_out, void* stream)
+{
+    if (!n_out || n < 0 || (n && !d_iq) || cap < 0 || (cap && (!triggers_host || !angles_host))) {
+        dtl::set_last_error("sync_sc: bad argument");
+        return DTL_ERR_INVALID_ARG;
+    }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    *n_out = 0;
+    if (n == 0) return DTL_OK;
+    if (n > int64_t(0x7fffffff)) { dtl::set_last_error("sync_sc: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
+    auto* st = static_cast<hipStream_t>(stream);
+    const auto* iq = reinterpret_cast<const dtl::cf32*>(d_iq);
+    dtl::DevBuf d_edges, d_cnt, d_trig, d_ang;
+    const unsigned max_edges = unsigned(std::min<int64_t>(std::max<int64_t>(n / 8, 1024), 1 << 26));
+    int rc = d_edges.ensure(size_t(max_edges) * 8);
+    if (rc == DTL_OK) rc = d_cnt.ensure(16);
+    if (rc != DTL_OK) return rc;
+    DTL_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 16, st));
+    rc = dtl::launch_sync_edges(iq, n, 0, fft_len, threshold, d_edges.as<unsigned long long>(), d_cnt.as<unsigned int>(),
+                                max_edges, d_metric, st);
+    if (rc != DTL_OK) return rc;
+    unsigned n_edges = 0;
+    DTL_HIP_CHECK(hipMemcpyAsync(&n_edges, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    if (n_edges > max_edges) { dtl::set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
+    std::vector<unsigned long long> edges(n_edges);
+    if (n_edges) DTL_HIP_CHECK(hipMemcpy(edges.data(), d_edges.p, size_t(n_edges) * 8, hipMemcpyDeviceToHost));
+    std::vector<int64_t> trig = dtl::plateau_from_edges(std::move(edges), n, cp_len);
+    *n_out = int64_t(trig.size());
+    if (int64_t(trig.size()) > cap) { dtl::set_last_error("sync_sc: trigger capacity too small"); return DTL_ERR_CAPACITY; }
+    if (trig.empty()) return DTL_OK;
+    rc = d_trig.ensure(trig.size() * 8);
+    if (rc == DTL_OK) rc = d_ang.ensure(trig.size() * 4);
+    if (rc != DTL_OK) return rc;
+    DTL_HIP_CHECK(hipMemcpyAsync(d_trig.p, trig.data(), trig.size() * 8, hipMemcpyHostToDevice, st));
+    rc = dtl::launch_trigger_angle(iq, n, fft_len, d_trig.as<int64_t>(), int(trig.size()), d_ang.as<float>(), st);
+    if (rc != DTL_OK) return rc;
+    DTL_HIP_CHECK(hipMemcpyAsync(angles_host, d_ang.p, trig.size() * 4, hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    std::copy(trig.begin(), trig.end(), triggers_host);
+    return DTL_OK;
+}
+
+int dtl_fft_batch(const float* d_in, float* d_out, int64_t n_vectors, int32_t fft_len, int32_t forward, void* stream)
+{
+    if (n_vectors < 0 || (n_vectors && (!d_in || !d_out))) { dtl::set_last_error("fft_batch: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    return dtl::launch_fft_batch(reinterpret_cast<const dtl::cf32*>(d_in), reinterpret_cast<dtl::cf32*>(d_out), n_vectors,
+                                 fft_len, forward, static_cast<hipStream_t>(stream));
+}
+
+int dtl_soft_demap(const float* d_syms, int64_t n_syms, int32_t constellation, double noise, int32_t dist_mode,
+                   float* d_llr, void* stream)
+{
+    if (n_syms < 0 || (n_syms && (!d_syms || !d_llr))) { dtl::set_last_error("soft_demap: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    return dtl::launch_soft_demap(reinterpret_cast<const dtl::cf32*>(d_syms), n_syms, constellation, noise, dist_mode, d_llr,
+                                  static_cast<hipStream_t>(stream));
+}
+
+int dtl_crc32(const uint8_t* d_bytes, int64_t len, uint32_t* crc_host, void* stream)
+{
+    if (!crc_host || len < 0 || (len && !d_bytes)) { dtl::set_last_error("crc32: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    auto* st = static_cast<hipStream_t>(stream);
+    dtl::DevBuf d_out;
+    int rc = d_out.ensure(16);
+    if (rc != DTL_OK) return rc;
+    rc = dtl::launch_crc32(d_bytes, len, d_out.as<uint32_t>(), st);
+    if (rc != DTL_OK) return rc;
+    DTL_HIP_CHECK(hipMemcpyAsync(crc_host, d_out.p, 4, hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    return DTL_OK;
+}
 
 int dtl_copy_device(void* dst, const void* src, size_t bytes, void* stream)
 {

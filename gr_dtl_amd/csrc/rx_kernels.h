@@ -31,6 +31,11 @@ int launch_expand_cw(const TbGather* tbs, int n_tbs, CwDesc* out, hipStream_t st
 int launch_nofec_lengths(const int32_t* info, int n, int32_t* len, hipStream_t st);
 int launch_compact(const uint8_t* staging, int stride, const int32_t* len, int n, uint32_t* offs,
                    uint32_t* total, uint8_t* out, hipStream_t st);
+// stand-alone stages (block shims, unit tests)
+void constellation_points_host(int cnst, cf32* out16);
+int launch_soft_demap(const cf32* syms, int64_t n, int cnst, double noise, int dist_mode, float* llr, hipStream_t st);
+int launch_fft_batch(const cf32* in, cf32* out, int64_t n_vec, int fft_len, int forward, hipStream_t st);
+int launch_crc32(const uint8_t* bytes, int64_t len, uint32_t* d_out, hipStream_t st);
 size_t header_lds_bytes(const RxTables& t);
 size_t payload_lds_bytes(const RxTables& t);
 

@@ -870,6 +870,92 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Stand-alone stages for block shims and unit tests (the fused kernels above are what the receive path
+// runs; these expose the same device arithmetic one block of the reference graph at a time).
+// ------------------------------------------------------------------------------------------
+struct CnstPoints {
+    cf32 p[16];
+};
+
+// ofdm_adaptive_constellation_soft_cf (soft_cf_impl.cc:89-148): bps soft bits per symbol, LSB first
+template <bool PLAIN_DIST>
+__global__ __launch_bounds__(256) void soft_demap_kernel(const cf32* __restrict__ syms, int64_t n, int bps, CnstPoints pts,
+                                                        double neg_inv_npwr, float* __restrict__ llr)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* o = llr + i * bps;
+    const cf32 s = syms[i];
+    switch (bps) {
+    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
+    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
+    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
+    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
+    }
+}
+
+// GR fft_vcc(fft_len, forward, window = (), shift = true): one workgroup of N/2 lanes per vector, the radix-2
+// butterflies and twiddle products of the receive / transmit kernels
+__global__ void fft_batch_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, int N, int forward,
+                                 const cf32* __restrict__ tw_g, const uint16_t* __restrict__ br_g)
+{
+    extern __shared__ unsigned char smem_raw[];
+    cf32* x = reinterpret_cast<cf32*>(smem_raw);
+    cf32* tw = x + N;
+    const int tid = threadIdx.x, hN = N / 2;
+    const cf32* src = in + size_t(blockIdx.x) * N;
+    cf32* dst = out + size_t(blockIdx.x) * N;
+    { // forward twiddles are exp(-j 2 pi k / N); the inverse transform uses their conjugates
+        cf32 w = tw_g[tid];
+        if (!forward) w.im = -w.im;
+        tw[tid] = w;
+    }
+    for (int k = tid; k < N; k += hN) {
+        const int from = forward ? k : ((k + hN) & (N - 1)); // inverse: swap halves first
+        x[br_g[k]] = src[from];
+    }
+    __syncthreads();
+    const int logN = __ffs(N) - 1;
+    for (int st = 0; st < logN; st++) {
+        const int half = 1 << st;
+        const int grp = tid >> st, k = tid & (half - 1);
+        const int a = (grp << (st + 1)) + k, b = a + half;
+        const cf32 w = tw[k << (logN - st - 1)];
+        const cf32 u = x[a];
+        const cf32 vv = cmul_tw(x[b], w);
+        x[a] = cadd(u, vv);
+        x[b] = csub(u, vv);
+        __syncthreads();
+    }
+    for (int k = tid; k < N; k += hN) dst[forward ? ((k + hN) & (N - 1)) : k] = x[k]; // forward: swap halves last
+}
+
+// CRC-32 of one byte string (crc_util.cc:41-61 / the CRC of ofdm_adaptive_frame_pack_bb), all 64 lanes
+__global__ __launch_bounds__(64) void crc32_kernel(const uint8_t* __restrict__ bytes, int64_t len,
+                                                  const uint32_t* __restrict__ zmat_g, uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t T[256];
+    __shared__ uint32_t zmat[32 * 32];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = uint32_t(i);
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+        T[i] = c;
+    }
+    for (int i = lane; i < 32 * 32; i += 64) zmat[i] = zmat_g[i];
+    __syncthreads();
+    const int64_t per = (len + 63) / 64;
+    const int64_t lo = min(int64_t(lane) * per, len), hi = min(lo + per, len);
+    uint32_t r = 0;
+    for (int64_t i = lo; i < hi; i++) r = T[(r ^ bytes[i]) & 0xFF] ^ (r >> 8);
+    r = crc32_shift(r, unsigned(len - hi), zmat);
+    if (lane == 0) r ^= crc32_shift(0xFFFFFFFFu, unsigned(len), zmat);
+    for (int o = 32; o > 0; o >>= 1) r ^= __shfl_xor(r, o);
+    if (lane == 0) *out = ~r;
+}
+
 // K9: transport-block reassembly as index arithmetic -- one CwDesc per codeword from the TB recipe.
 // Codeword i carries k_i = floor(P/n) + (i < P mod n) payload bits (the iterated ceil split of
 // tb_decoder.cc:168-172) and starts at receive-buffer position i*ncheck + sum_{j<i} k_j.
@@ -1124,6 +1210,122 @@ int launch_compact(const uint8_t* staging, int stride, const int32_t* len, int n
     if (n <= 0) { DTL_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint32_t), st)); return DTL_OK; }
     hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, st, len, n, offs, total);
     hipLaunchKernelGGL(compact_kernel, dim3(n), dim3(128), 0, st, staging, stride, len, offs, n, out);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+
+// ---- launchers of the stand-alone stages
+void constellation_points_host(int cnst, cf32* out16)
+{
+    for (int i = 0; i < 16; i++) out16[i] = { 0.0f, 0.0f };
+    switch (cnst) {
+    case 1: out16[0] = { -1, 0 }; out16[1] = { 1, 0 }; break;
+    case 2: {
+        const float s = float(double(float(0.707107)) * 0.5); // SQRT_TWO macro, lib/dtl/constellation.cc:19-23
+        out16[0] = { -s, -s }; out16[1] = { s, -s }; out16[2] = { -s, s }; out16[3] = { s, s };
+    } break;
+    case 3: {
+        const float angle = float(M_PI / 8.0);
+        const int mult[8] = { 1, 7, 15, 9, 3, 5, 13, 11 };
+        for (int i = 0; i < 8; i++) out16[i] = { float(std::cos(mult[i] * angle)), float(std::sin(mult[i] * angle)) };
+    } break;
+    case 4: {
+        const float level = std::sqrt(float(0.1));
+        for (int i = 0; i < 16; i++)
+            out16[i] = { ((i & 2) ? 3 : 1) * level * ((i & 4) ? -1.f : 1.f), ((i & 1) ? 3 : 1) * level * ((i & 8) ? 1.f : -1.f) };
+    } break;
+    default: break;
+    }
+}
+
+int launch_soft_demap(const cf32* syms, int64_t n, int cnst, double noise, int dist_mode, float* llr, hipStream_t st)
+{
+    if (n <= 0) return DTL_OK;
+    if (cnst < 1 || cnst > 4) { set_last_error("Unknown constellation"); return DTL_ERR_INVALID_ARG; }
+    CnstPoints pts;
+    constellation_points_host(cnst, pts.p);
+    // soft_cf_impl.cc:89-103: sigma = sqrt(noise), or 0.001 when no estimate is available
+    double sigma = 0.001;
+    if (noise >= 0) sigma = std::sqrt(noise);
+    const double neg_inv_npwr = -1.0 / double(float(sigma));
+    const int64_t grid = (n + 255) / 256;
+    if (dist_mode) hipLaunchKernelGGL(soft_demap_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, neg_inv_npwr, llr);
+    else hipLaunchKernelGGL(soft_demap_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, neg_inv_npwr, llr);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+int launch_fft_batch(const cf32* in, cf32* out, int64_t n_vec, int N, int forward, hipStream_t st)
+{
+    if (n_vec <= 0) return DTL_OK;
+    if (N < 4 || N > 2048 || (N & (N - 1))) { set_last_error("fft_batch: fft_len must be a power of two in [4, 2048]"); return DTL_ERR_INVALID_ARG; }
+    // twiddle / bit-reversal tables per transform length, built once per process and device
+    struct Tab { int N, dev; cf32* tw; uint16_t* br; };
+    static std::vector<Tab> tabs;
+    int dev = 0;
+    DTL_HIP_CHECK(hipGetDevice(&dev));
+    const Tab* t = nullptr;
+    for (const auto& e : tabs) if (e.N == N && e.dev == dev) t = &e;
+    if (!t) {
+        std::vector<cf32> tw(N / 2);
+        for (int k = 0; k < N / 2; k++) { const double ang = -2.0 * M_PI * k / N; tw[k] = { float(std::cos(ang)), float(std::sin(ang)) }; }
+        std::vector<uint16_t> br(N);
+        int logn = 0;
+        while ((1 << logn) < N) logn++;
+        for (int i = 0; i < N; i++) { int r = 0; for (int b = 0; b < logn; b++) if (i & (1 << b)) r |= 1 << (logn - 1 - b); br[i] = uint16_t(r); }
+        Tab e{ N, dev, nullptr, nullptr };
+        DTL_HIP_CHECK(hipMalloc(&e.tw, tw.size() * sizeof(cf32)));
+        DTL_HIP_CHECK(hipMalloc(&e.br, br.size() * 2));
+        DTL_HIP_CHECK(hipMemcpy(e.tw, tw.data(), tw.size() * sizeof(cf32), hipMemcpyHostToDevice));
+        DTL_HIP_CHECK(hipMemcpy(e.br, br.data(), br.size() * 2, hipMemcpyHostToDevice));
+        tabs.push_back(e);
+        t = &tabs.back();
+    }
+    const size_t lds = size_t(N + N / 2) * sizeof(cf32);
+    hipLaunchKernelGGL(fft_batch_kernel, dim3((unsigned)n_vec), dim3(N / 2), lds, st, in, out, N, forward, t->tw, t->br);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+static int crc_zero_maps(uint32_t** out, int levels)
+{
+    static uint32_t* d_z = nullptr;
+    static int z_dev = -1;
+    int dev = 0;
+    DTL_HIP_CHECK(hipGetDevice(&dev));
+    if (!d_z || z_dev != dev) {
+        uint32_t T[256];
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+            T[i] = c;
+        }
+        std::vector<uint32_t> z(32 * 32);
+        for (int b = 0; b < 32; b++) { const uint32_t v = 1u << b; z[b] = T[v & 0xFF] ^ (v >> 8); }
+        for (int j = 1; j < 32; j++)
+            for (int b = 0; b < 32; b++) {
+                uint32_t v = z[(j - 1) * 32 + b], acc = 0;
+                for (int c = 0; c < 32; c++) if ((v >> c) & 1u) acc ^= z[(j - 1) * 32 + c];
+                z[j * 32 + b] = acc;
+            }
+        uint32_t* p = nullptr;
+        DTL_HIP_CHECK(hipMalloc(&p, z.size() * 4));
+        DTL_HIP_CHECK(hipMemcpy(p, z.data(), z.size() * 4, hipMemcpyHostToDevice));
+        d_z = p; z_dev = dev;
+    }
+    (void)levels;
+    *out = d_z;
+    return DTL_OK;
+}
+
+int launch_crc32(const uint8_t* bytes, int64_t len, uint32_t* d_out, hipStream_t st)
+{
+    if (len < 0 || len > int64_t(0xFFFFFFFFu)) { set_last_error("crc32: at most 2^32-1 bytes"); return DTL_ERR_INVALID_ARG; }
+    uint32_t* z = nullptr;
+    int rc = crc_zero_maps(&z, 32);
+    if (rc != DTL_OK) return rc;
+    hipLaunchKernelGGL(crc32_kernel, dim3(1), dim3(64), 0, st, bytes, len, z, d_out);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

@@ -229,6 +229,28 @@ int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t con
                    int32_t first_frame_no, int32_t first_tb_no, int32_t gap, int32_t want_syms, void* stream,
                    dtl_tx_result* out);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Single stages of the receive graph, for block shims and unit tests (the receiver above runs fused kernels
+ * with the same device arithmetic).  Device pointers unless named *_host.
+ * ------------------------------------------------------------------------------------------------- */
+/* GR ofdm_sync_sc_cfb as wired at python/dtl/ofdm_receiver.py:71-72 + sample_and_hold of arg(P): optional
+ * timing metric per sample (d_metric, n floats, may be NULL), trigger positions and the angle held at each
+ * trigger (host arrays of capacity `cap`; *n_out = triggers found, DTL_ERR_CAPACITY when cap is too small) */
+int dtl_sync_sc(const float* d_iq, int64_t n_samples, int32_t fft_len, int32_t cp_len, float threshold,
+                float* d_metric, int64_t* triggers_host, float* angles_host, int64_t cap, int64_t* n_out,
+                void* stream);
+/* GR fft_vcc(fft_len, forward, (), shift = true) on n_vectors vectors of fft_len complex samples
+ * (python/dtl/ofdm_receiver.py:116-121, python/dtl/ofdm_transmitter.py:172-178); unnormalised */
+int dtl_fft_batch(const float* d_in, float* d_out, int64_t n_vectors, int32_t fft_len, int32_t forward, void* stream);
+/* ofdm_adaptive_constellation_soft_cf (lib/dtl/ofdm_adaptive_constellation_soft_cf_impl.cc:89-148): n symbols of
+ * one constellation, noise = the equaliser's linear noise estimate (< 0: none, sigma 0.001) -> bits/symbol soft
+ * bits per symbol, LSB first; dist_mode as in dtl_rx_cfg.llr_dist_mode */
+int dtl_soft_demap(const float* d_syms, int64_t n_syms, int32_t constellation, double noise, int32_t dist_mode,
+                   float* d_llr, void* stream);
+/* CRC-32 of a device byte string, as lib/dtl/crc_util.cc:41-61 computes it (crc(32, 0x04C11DB7, ~0, ~0, refin,
+ * refout)); the value is returned to the host (the call synchronises `stream`) */
+int dtl_crc32(const uint8_t* d_bytes, int64_t len, uint32_t* crc_host, void* stream);
+
 /* device-to-device copy on `stream` (lets a host binding snapshot result buffers it does not own) */
 int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);
 
