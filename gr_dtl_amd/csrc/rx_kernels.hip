@@ -560,11 +560,29 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
     for (int m = 0; m < M; m++) lp[m] = pts[m];
 #pragma unroll
     for (int j = 0; j < BPS; j++) { p0[j] = 0.0f; p1[j] = 0.0f; }
+    // 16-QAM is a 4 x 4 grid (real part chosen by index bits 1-2, imaginary part by bits 0 and 3): the sixteen
+    // squared component distances are four + four distinct values; computing each once gives the same floats
+    float dr2[4], di2[4];
+    if (BPS == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float dr = s.re - lp[q << 1].re;                        // points 0, 2, 4, 6: the four real levels
+            const float di = s.im - lp[(q & 1) | ((q >> 1) << 3)].im;     // points 0, 1, 8, 9: the four imaginary levels
+            dr2[q] = dr * dr;
+            di2[q] = di * di;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < M; m++) {
-        const float dr = s.re - lp[m].re, di = s.im - lp[m].im;
+        float sq;
+        if (BPS == 4) {
+            sq = dr2[(m >> 1) & 3] + di2[(m & 1) | ((m >> 3) << 1)];
+        } else {
+            const float dr = s.re - lp[m].re, di = s.im - lp[m].im;
+            sq = dr * dr + di * di;
+        }
         // compile-time switch: a runtime select would evaluate the correctly rounded sqrtf for every point
-        const float dist = PLAIN_DIST ? sqrtf(dr * dr + di * di) : (dr * dr + di * di);
+        const float dist = PLAIN_DIST ? sqrtf(sq) : sq;
         const float d = dm_exp(float(double(dist) * neg_inv_npwr)); // fixed-sequence expf (dtl_math.h)
 #pragma unroll
         for (int j = 0; j < BPS; j++) {
