@@ -194,6 +194,18 @@ int dtl_tx_create(const dtl_rx_cfg* c, dtl_tx** out)
 
 void dtl_tx_destroy(dtl_tx* h) { delete h; }
 
+int dtl_tx_plan(dtl_tx* h, int64_t n_user, int32_t constellation, int32_t fec, int32_t first_frame_no,
+                int32_t first_tb_no, dtl_tx_frame_info* frames_out, int64_t cap, int64_t* n_out)
+{
+    if (!h || !n_out || n_user < 0 || cap < 0 || (cap && !frames_out)) { dtl::set_last_error("tx_plan: bad argument"); return DTL_ERR_INVALID_ARG; }
+    int rc = h->tx.plan(n_user, constellation, fec, first_frame_no, first_tb_no);
+    if (rc != DTL_OK) return rc;
+    *n_out = int64_t(h->tx.frames.size());
+    if (*n_out > cap) { dtl::set_last_error("tx_plan: frame capacity too small"); return DTL_ERR_CAPACITY; }
+    std::memcpy(frames_out, h->tx.frames.data(), h->tx.frames.size() * sizeof(dtl_tx_frame_info));
+    return DTL_OK;
+}
+
 int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t constellation, int32_t fec,
                    int32_t first_frame_no, int32_t first_tb_no, int32_t gap, int32_t want_syms, void* stream,
                    dtl_tx_result* out)

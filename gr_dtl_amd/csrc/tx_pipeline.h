@@ -76,9 +76,11 @@ public:
     int frame_samples() const { return (2 + cfg.header_len() + cfg.frame_length) * (cfg.fft_len + cfg.cp_len); }
     int hdr_bits() const { return cfg.header_len() * int(cfg.occupied_carriers[0].size()); }
 
+    // framing state machine on lengths (host only): fills `frames` and the internal gather tables
+    int plan(int64_t n_user, int cnst, int fec, int first_frame_no, int first_tb_no);
+
 private:
     int upload_tables();
-    int plan(int64_t n_user, int cnst, int fec, int first_frame_no, int first_tb_no);
     bool uploaded_ = false;
     int capacity_ = 0;
     std::vector<LdpcCode> codes_; // index 0 unused ("no FEC")

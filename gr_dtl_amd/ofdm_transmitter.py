@@ -293,6 +293,24 @@ class ofdm_transmitter:
         except Exception:
             pass
 
+    def plan_device(self, n_user, constellation, fec_scheme=None, first_frame_no=0, first_tb_no=0):
+        """Header records of the frames work_device() would emit for n_user bytes (host only: the framing state
+        machine of the C++ side evaluated on lengths)."""
+        from . import _lib
+        h = self._device_handle()
+        L = _lib.lib()
+        L.dtl_tx_plan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                  C.POINTER(C.c_int64)]
+        fec_idx = 0
+        if self.fec:
+            fec_idx = self.codes_id[fec_scheme] if isinstance(fec_scheme, str) else int(fec_scheme)
+        cap = int(n_user) // 8 + 64
+        out = np.zeros(cap, dtype=_TXF_DTYPE)
+        n_out = C.c_int64(0)
+        _lib.check(L.dtl_tx_plan(h, int(n_user), int(constellation), fec_idx, int(first_frame_no), int(first_tb_no),
+                                 out.ctypes.data, cap, C.byref(n_out)))
+        return out[:int(n_out.value)].copy()
+
     def work_device(self, user, constellation, fec_scheme=None, first_frame_no=0, first_tb_no=0, gap=0,
                     want_syms=False):
         """user: uint8 CUDA tensor.  -> (iq complex64 CUDA tensor [n_frames, frame_samples + gap], header records

@@ -225,6 +225,10 @@ void dtl_tx_destroy(dtl_tx* h);
 /* d_user: n_user bytes on the device; constellation 1..4; fec = FEC id (0 / ignored without FEC);
  * first_frame_no / first_tb_no continue the numbering of a previous call (mixed-MCS streams);
  * gap = zero samples appended to every frame; want_syms != 0 also returns the symbol indices. */
+/* The framing state machine alone (host only, no device needed): the packet-header fields of the frames that
+ * dtl_tx_process would emit for n_user bytes.  *n_out = frames; DTL_ERR_CAPACITY when cap is too small. */
+int dtl_tx_plan(dtl_tx* h, int64_t n_user, int32_t constellation, int32_t fec, int32_t first_frame_no,
+                int32_t first_tb_no, dtl_tx_frame_info* frames_out, int64_t cap, int64_t* n_out);
 int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t constellation, int32_t fec,
                    int32_t first_frame_no, int32_t first_tb_no, int32_t gap, int32_t want_syms, void* stream,
                    dtl_tx_result* out);

@@ -145,3 +145,36 @@ def test_config_mirror_defaults(dtl):
     assert rx.frame_capacity == 960 and rx.frame_samples == 1920
     scaled = dtl.make_scaled_rx_config(256)
     assert len(scaled.occupied_carriers[0]) == 192 and len(scaled.pilot_carriers[0]) == 16
+
+
+def test_tx_framing_state_machine_matches_oracle(oracle, dtl):
+    """dtl_tx_plan (host only): the header fields of every frame the GPU transmitter would emit equal those of the
+    oracle's restatement of ofdm_adaptive_fec_frame_bvb / ofdm_adaptive_frame_bb, for all constellations, odd sizes,
+    frame lengths and numbering offsets."""
+    import os
+    from conftest import CODES
+    from gr_dtl_amd.ofdm_transmitter import ofdm_transmitter
+    code = oracle.Ldpc(os.path.join(CODES, "n_0300_k_0152_gap_03.alist"))
+    keys = ("payload_len", "frame_no", "cnst", "fb_cnst", "tb_no", "fec_fb", "tb_offset", "fec", "tb_payload")
+    rng = np.random.default_rng(9)
+    for fft_len, frame_length in ((64, 20), (64, 5), (256, 10)):
+        cfg = dtl.ofdm_adaptive_rx_config(frame_length=frame_length) if fft_len == 64 else \
+            dtl.make_scaled_rx_config(fft_len, frame_length=frame_length)
+        cfg.fec_codes = (("fec_1", "n_0300_k_0152_gap_03.alist"),)
+        tx = ofdm_transmitter(cfg)
+        for cnst in (1, 2, 3, 4):
+            for nbytes in (1, 117, 118, 119, 1000, int(rng.integers(2000, 9000))):
+                user = rng.integers(0, 256, nbytes, dtype=np.uint8)
+                _, ref = oracle.fec_frames_build(code, 1, cnst, tx.frame_capacity, user, first_frame_no=4000)
+                got = tx.plan_device(nbytes, cnst, "fec_1", first_frame_no=4000)
+                assert len(got) == len(ref), (fft_len, frame_length, cnst, nbytes)
+                for k in keys:
+                    assert list(got[k]) == [h[k] for h in ref], (fft_len, frame_length, cnst, nbytes, k)
+    cfg = dtl.ofdm_adaptive_rx_config()
+    tx = ofdm_transmitter(cfg)          # no FEC
+    for cnst in (1, 2, 3, 4):
+        user = rng.integers(0, 256, 5000, dtype=np.uint8)
+        _, ref = oracle.nofec_frames_build(cnst, tx.frame_capacity, user, first_frame_no=3)
+        got = tx.plan_device(5000, cnst, first_frame_no=3)
+        assert [int(v) for v in got["payload_len"]] == [h["payload_len"] for h in ref]
+        assert [int(v) for v in got["frame_no"]] == [h["frame_no"] for h in ref]
