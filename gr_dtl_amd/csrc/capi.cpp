@@ -194,6 +194,15 @@ int dtl_tx_create(const dtl_rx_cfg* c, dtl_tx** out)
 
 void dtl_tx_destroy(dtl_tx* h) { delete h; }
 
+int dtl_header_format_host(const dtl_tx_frame_info* fields, int32_t has_fec, int32_t header_len_bits, uint8_t* bits_out)
+{
+    if (!fields || !bits_out || header_len_bits < 16) { dtl::set_last_error("header_format: bad argument"); return DTL_ERR_INVALID_ARG; }
+    dtl::TxFrameInfo f;
+    std::memcpy(&f, fields, sizeof(f));
+    dtl::format_header_bits(f, has_fec != 0, header_len_bits, bits_out);
+    return DTL_OK;
+}
+
 int dtl_tx_plan(dtl_tx* h, int64_t n_user, int32_t constellation, int32_t fec, int32_t first_frame_no,
                 int32_t first_tb_no, dtl_tx_frame_info* frames_out, int64_t cap, int64_t* n_out)
 {

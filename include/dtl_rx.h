@@ -225,6 +225,9 @@ void dtl_tx_destroy(dtl_tx* h);
 /* d_user: n_user bytes on the device; constellation 1..4; fec = FEC id (0 / ignored without FEC);
  * first_frame_no / first_tb_no continue the numbering of a previous call (mixed-MCS streams);
  * gap = zero samples appended to every frame; want_syms != 0 also returns the symbol indices. */
+/* ofdm_adaptive_packet_header::header_formatter (lib/dtl/ofdm_adaptive_packet_header.cc:141-199) on the host: the
+ * header bits (1 per byte, header_len_bits of them) the transmitter puts on the header symbols */
+int dtl_header_format_host(const dtl_tx_frame_info* fields, int32_t has_fec, int32_t header_len_bits, uint8_t* bits_out);
 /* The framing state machine alone (host only, no device needed): the packet-header fields of the frames that
  * dtl_tx_process would emit for n_user bytes.  *n_out = frames; DTL_ERR_CAPACITY when cap is too small. */
 int dtl_tx_plan(dtl_tx* h, int64_t n_user, int32_t constellation, int32_t fec, int32_t first_frame_no,

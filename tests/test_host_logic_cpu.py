@@ -178,3 +178,25 @@ def test_tx_framing_state_machine_matches_oracle(oracle, dtl):
         got = tx.plan_device(5000, cnst, first_frame_no=3)
         assert [int(v) for v in got["payload_len"]] == [h["payload_len"] for h in ref]
         assert [int(v) for v in got["frame_no"]] == [h["frame_no"] for h in ref]
+
+
+def test_product_header_formatter_against_reference_rows(dtl):
+    """The product's host-side header formatter (the bits the GPU transmitter modulates) reproduces the six header
+    bit rows of the reference's own QA test (tests/golden, qa_ofdm_adaptive_packet_header.py:73-260), CRC-16 included."""
+    import ctypes as C
+    import json
+    import os
+    from conftest import GOLDEN
+    from gr_dtl_amd.ofdm_transmitter import TxFrameInfo
+    G = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))
+    L = dtl._lib.lib()
+    L.dtl_header_format_host.argtypes = [C.POINTER(TxFrameInfo), C.c_int32, C.c_int32, C.c_void_p]
+    for key, has_fec, nbits in (("packet_header_no_fec", 0, 48), ("packet_header_fec", 1, 96)):
+        g = G[key]
+        for i, bits in enumerate(g["bits"]):
+            f = TxFrameInfo(payload_len=g["packets_len"][i], frame_no=i, cnst=g["constellations"][i], fb_cnst=0)
+            if has_fec:
+                f.tb_no, f.tb_offset, f.fec, f.tb_payload = g["fec"][i]
+            out = np.zeros(nbits, np.uint8)
+            assert L.dtl_header_format_host(C.byref(f), has_fec, nbits, out.ctypes.data) == 0
+            assert out.tolist() == bits, (key, i)
