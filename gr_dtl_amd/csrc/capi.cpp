@@ -194,6 +194,16 @@ int dtl_tx_create(const dtl_rx_cfg* c, dtl_tx** out)
 
 void dtl_tx_destroy(dtl_tx* h) { delete h; }
 
+int dtl_constellation_points_host(int32_t constellation, float* points16, int32_t* n_points)
+{
+    if (!points16 || !n_points || constellation < 1 || constellation > 4) { dtl::set_last_error("Unknown constellation"); return DTL_ERR_INVALID_ARG; }
+    dtl::cf32 p[16];
+    dtl::constellation_points_host(constellation, p);
+    std::memcpy(points16, p, sizeof(p));
+    *n_points = 1 << constellation;
+    return DTL_OK;
+}
+
 int dtl_header_format_host(const dtl_tx_frame_info* fields, int32_t has_fec, int32_t header_len_bits, uint8_t* bits_out)
 {
     if (!fields || !bits_out || header_len_bits < 16) { dtl::set_last_error("header_format: bad argument"); return DTL_ERR_INVALID_ARG; }

@@ -225,6 +225,10 @@ void dtl_tx_destroy(dtl_tx* h);
 /* d_user: n_user bytes on the device; constellation 1..4; fec = FEC id (0 / ignored without FEC);
  * first_frame_no / first_tb_no continue the numbering of a previous call (mixed-MCS streams);
  * gap = zero samples appended to every frame; want_syms != 0 also returns the symbol indices. */
+/* The constellation tables the kernels use (host only): gr::digital constellation_{bpsk,qpsk,8psk,16qam} with
+ * gr-dtl's 0.5 scaling of QPSK (lib/dtl/constellation.cc:18-24, lib/dtl/ofdm_adaptive_utils.cc:52-70); 16 complex
+ * (re, im) slots, *n_points of them valid */
+int dtl_constellation_points_host(int32_t constellation, float* points16, int32_t* n_points);
 /* ofdm_adaptive_packet_header::header_formatter (lib/dtl/ofdm_adaptive_packet_header.cc:141-199) on the host: the
  * header bits (1 per byte, header_len_bits of them) the transmitter puts on the header symbols */
 int dtl_header_format_host(const dtl_tx_frame_info* fields, int32_t has_fec, int32_t header_len_bits, uint8_t* bits_out);

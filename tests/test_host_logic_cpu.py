@@ -200,3 +200,27 @@ def test_product_header_formatter_against_reference_rows(dtl):
             out = np.zeros(nbits, np.uint8)
             assert L.dtl_header_format_host(C.byref(f), has_fec, nbits, out.ctypes.data) == 0
             assert out.tolist() == bits, (key, i)
+
+
+def test_product_constellation_tables_against_reference_constants(oracle, dtl):
+    """The tables the kernels slice / demap with: 8PSK[0] = e^{j pi/8}, BPSK[0] = -1 and the metric constant of the
+    reference's QA test (qa_ofdm_adaptive_constellation_metric_vcvf.py:86); bit-identical to the oracle's tables."""
+    import ctypes as C
+    import json
+    import os
+    from conftest import GOLDEN
+    G = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))
+    L = dtl._lib.lib()
+    L.dtl_constellation_points_host.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+    pts = {}
+    for cnst in (1, 2, 3, 4):
+        buf = np.zeros(16, np.complex64)
+        n = C.c_int32(0)
+        assert L.dtl_constellation_points_host(cnst, buf.ctypes.data, C.byref(n)) == 0 and n.value == 1 << cnst
+        pts[cnst] = buf[:n.value]
+        np.testing.assert_array_equal(pts[cnst].view(np.uint32), oracle.constellation_points(cnst).view(np.uint32))
+    p8, pb = pts[3], pts[1]
+    dmin2 = min(abs(p8[i] - p8[j]) ** 2 for i in range(8) for j in range(i))
+    assert abs(abs(p8[0] - pb[0]) ** 2 / dmin2 - G["constellation_metric"]["value"]) < 1e-5
+    assert abs(p8[0] - np.exp(1j * np.pi / 8)) < 1e-6 and pb[0] == -1
+    assert L.dtl_constellation_points_host(9, buf.ctypes.data, C.byref(n)) == dtl._lib.ERR_INVALID_ARG
