@@ -606,50 +606,42 @@ __device__ __forceinline__ Welford welford_merge(Welford a, Welford b)
     return { n, a.mean + d * (b.n / n), a.m2 + b.m2 + d * d * (a.n * b.n / n) };
 }
 
-__global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
-                               const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
-                               int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
-                               const uint32_t* __restrict__ llr_off, float* __restrict__ llr_out,
-                               cf32* __restrict__ eq_hard, cf32* __restrict__ eq_soft,
-                               cf32* __restrict__ soft_syms, uint8_t* __restrict__ nofec_bytes,
-                               int32_t* __restrict__ nofec_info, int nofec_stride)
+// Phase B is two kernels.  frame_eq_kernel needs barriers and LDS (FFT) but no more than four symbols of it:
+// the frame equaliser is sequential over the symbols of ONE carrier, so a lane can equalise the four
+// symbols of a batch as soon as they are transformed, and nothing forces the frame to stay resident --
+// 9 KB of LDS per workgroup instead of 49 KB, eight workgroups per CU instead of three.  The soft demapper
+// needs the noise estimate of the whole frame and therefore runs afterwards, as a plain element-wise kernel
+// at full occupancy (demap_kernel); the equalised symbols cross HBM once in between (8 B per data symbol).
+//
+// Integer carrier offset (`off`, :154-166 of the frame equaliser): destination (symbol i, carrier k) takes
+// the FFT output at flattened position i N + k + off, zero outside the frame.  For a fixed carrier k the
+// source is always column (k + off) mod N of row i + lag with ONE lag in {-1, 0, +1}: the lane walks the
+// source rows in order and equalises destination symbol (row - lag); the zero symbol comes first (lag -1)
+// or last (lag +1).
+__global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
+                                const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
+                                int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
+                                cf32* __restrict__ eq_hard, cf32* __restrict__ eq_soft,
+                                cf32* __restrict__ soft_syms)
 {
     extern __shared__ unsigned char smem_raw[];
     const int N = t.fft_len, L = t.frame_length, tid = threadIdx.x, h = t.header_len;
     cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // 4 x N : FFT scratch (four symbols per batch)
-    cf32* frame = buf + 4 * N;                        // L x N : shifted/derotated FFT output -> soft symbols
-    Welford* wred = reinterpret_cast<Welford*>(frame + size_t(L) * N); // blockDim/64 partials
-    cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64);          // N/2 twiddles
+    Welford* wred = reinterpret_cast<Welford*>(buf + 4 * N); // blockDim/64 partials
+    cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64); // N/2 twiddles
     if (tid < N / 2) tw[tid] = t.twiddle[tid];
-    __shared__ FrameStat s_stat;
 
     const FrameDesc fd = frames[blockIdx.x];
     const int off = fd.carr_offset;
     const int total = L * N;
-
     const SegWindow sw = seg_window(segs, n_segs, fd.seg);
-    // zero fill of the integer-CFO shift (:154-166)
-    if (off < 0) { for (int p = tid; p < -off; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
-    else { for (int p = total - off + tid; p < total; p += blockDim.x) frame[p] = { 0.0f, 0.0f }; }
-    for (int i0 = 0; i0 < L; i0 += 4) {
-        const int nb = min(4, L - i0);
-        load_and_fft4(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
-        // out[p - off] = in[p], then out *= expj(-2 pi off cp / N (sym+1)) with sym of the destination
-        for (int u = 0; u < nb; u++) {
-            const int p = (i0 + u) * N + tid;
-            const int dst = p - off;
-            if (dst >= 0 && dst < total) {
-                const cf32 v = buf[u * N + ((tid + N / 2) & (N - 1))];
-                cf32 pc = { 1.0f, -0.0f }; // expj(-0.0f): the value the formula below takes for off == 0
-                if (off != 0) pc = expj(float(-(2.0 * kPi) * off * t.cp_len / N * (dst / N + 1)));
-                frame[dst] = cmul(v, pc);
-            }
-        }
-        __syncthreads();
-    }
 
-    // frame_equalize: lane == subcarrier, sequential over the L symbols
+    // lane == destination carrier (shifted position k)
     const int k = tid;
+    int lag = 0, ks = k + off;
+    if (ks >= N) { lag = 1; ks -= N; }
+    else if (ks < 0) { lag = -1; ks += N; }
+    const int bin = (ks + N / 2) & (N - 1);           // natural-order FFT bin of the source column
     cf32 Hk = taps_in[size_t(fd.cand) * N + k];
     const float alpha = t.eq_alpha;
     const bool occupied = t.occupied[k] != 0;
@@ -658,10 +650,13 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
     int pilot_carr_set = t.n_pilot_sets ? h % t.n_pilot_sets : 0;
     cf32* hard_row = eq_hard ? eq_hard + size_t(blockIdx.x) * total : nullptr;
     cf32* soft_row = eq_soft ? eq_soft + size_t(blockIdx.x) * total : nullptr;
-    for (int i = 0; i < L; i++) {
+    cf32* soft_out = soft_syms + size_t(blockIdx.x) * t.frame_capacity;
+    int q_base = 0;                                   // data symbols in front of destination symbol i (serializer order)
+
+    // frame_equalize for destination symbol i of this carrier (ofdm_adaptive_equalizer.cc:217-268)
+    auto eq_step = [&](int i, cf32 y) {
         const int pset = (h + i) % t.n_pilot_sym_sets;
         const bool is_pilot = t.n_pilot_sets && t.pilot_mask[pilot_carr_set * N + k];
-        const cf32 y = frame[i * N + k];
         cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
         // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
         // tap towards y / (known or decided symbol) -- so the two cases share one pair of complex divisions
@@ -696,9 +691,32 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
         }
         if (hard_row) hard_row[i * N + k] = hard_v;
         if (soft_row) soft_row[i * N + k] = soft_v;
-        frame[i * N + k] = soft_v; // the serializer / demapper read the soft output
+        // ofdm_serializer_vcc (symbols_skipped = 1): data carrier r of OFDM symbol i is symbol q_base + r
+        const int set = (1 + i) % t.n_occ_sets;
+        const int r = t.occ_rank[set * N + k];
+        if (r >= 0 && q_base + r < fd.n_syms) soft_out[q_base + r] = soft_v;
+        q_base += t.occ_len[set];
         if (t.n_pilot_sets) pilot_carr_set = (pilot_carr_set + 1) % t.n_pilot_sets;
+    };
+
+    if (lag < 0) eq_step(0, cf32{ 0.0f, 0.0f });      // its source would be row -1: the zero fill of the shift
+    for (int i0 = 0; i0 < L; i0 += 4) {
+        const int nb = min(4, L - i0);
+        load_and_fft4(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
+        for (int u = 0; u < nb; u++) {
+            const int i = i0 + u - lag;               // destination symbol fed by source row i0 + u
+            if (i >= 0 && i < L) {
+                const cf32 v = buf[u * N + bin];
+                // out *= expj(-2 pi off cp / N (sym + 1)) with sym of the destination
+                cf32 pc = { 1.0f, -0.0f };            // expj(-0.0f): the value the formula takes for off == 0
+                if (off != 0) pc = expj(float(-(2.0 * kPi) * off * t.cp_len / N * (i + 1)));
+                eq_step(i, cmul(v, pc));
+            }
+        }
+        __syncthreads();                              // the next batch overwrites the scratch rows
     }
+    if (lag > 0) eq_step(L - 1, cf32{ 0.0f, 0.0f });  // its source would be row L
+
     // combine the per-carrier Welford states (Chan); double, fixed tree order
     for (int o = 32; o > 0; o >>= 1) {
         Welford other = { __shfl_down(w.n, o), __shfl_down(w.mean, o), __shfl_down(w.m2, o) };
@@ -712,98 +730,79 @@ __global__ void payload_kernel(RxTables t, const cf32* __restrict__ iq, int64_t 
         // mpsk_snr_est_simple::snr()/noise(); get_noise() (equalizer.cc:279-287)
         const double signal_db = 10.0 * log10(fabs(a.mean * a.mean));
         const double noise_db = 10.0 * log10(2.0 * a.m2 / a.n);
-        s_stat = { signal_db - noise_db, noise_db, pow(10.0, noise_db / 10.0) };
-        stats[blockIdx.x] = s_stat;
+        stats[blockIdx.x] = { signal_db - noise_db, noise_db, pow(10.0, noise_db / 10.0) };
+    }
+}
+
+// ofdm_adaptive_constellation_soft_cf over all frames of a batch: thread == data symbol (blockIdx.x == frame)
+template <bool PLAIN_DIST>
+__global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc* __restrict__ frames,
+                                                   const FrameStat* __restrict__ stats,
+                                                   const cf32* __restrict__ soft_syms,
+                                                   const uint32_t* __restrict__ llr_off, float* __restrict__ llr_out)
+{
+    const int f = blockIdx.x;
+    const int n_syms = frames[f].n_syms;              // payload == 0: frame dropped after the equaliser (:218,254)
+    const int q = blockIdx.y * blockDim.x + threadIdx.x;
+    if (q >= n_syms) return;
+    const int cnst = frames[f].cnst;
+    const int bps = cnst == 4 ? 4 : cnst;
+    const cf32* pts = t.cnst_pts + cnst * 16;
+    const float npwr = float(sqrt(stats[f].noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
+    const double neg_inv_npwr = -1.0 / double(npwr);
+    const cf32 s = soft_syms[size_t(f) * t.frame_capacity + q];
+    float* o = llr_out + size_t(llr_off[f]) + size_t(q) * bps;
+    switch (bps) {
+    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
+    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
+    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
+    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
+    }
+}
+
+// no-FEC tail: ofdm_adaptive_constellation_decoder_cb + ofdm_adaptive_frame_pack_bb; the soft symbols are
+// sliced with the decision makers of the GR constellations, repacked bps -> 8 LSB first, CRC-32 checked.
+__global__ __launch_bounds__(256) void nofec_tail_kernel(RxTables t, const FrameDesc* __restrict__ frames,
+                                                        const cf32* __restrict__ soft_syms,
+                                                        uint8_t* __restrict__ nofec_bytes, int32_t* __restrict__ nofec_info,
+                                                        int nofec_stride)
+{
+    const FrameDesc fd = frames[blockIdx.x];
+    if (fd.n_syms <= 0) return;
+    const int tid = threadIdx.x;
+    const int bps = fd.cnst == 4 ? 4 : fd.cnst;
+    const cf32* soft = soft_syms + size_t(blockIdx.x) * t.frame_capacity;
+    uint8_t* bytes = nofec_bytes + size_t(blockIdx.x) * nofec_stride;
+    const int n_bits = fd.n_syms * bps;
+    int n_written = n_bits / 8 + ((n_bits % 8) ? 1 : 0);
+    if (n_bits % 8) --n_written;
+    for (int b = tid; b < n_written; b += blockDim.x) {
+        unsigned v = 0;
+        for (int j = 0; j < 8; j++) {
+            const int bit = b * 8 + j, q = bit / bps, jb = bit % bps;
+            const cf32 s = soft[q];
+            unsigned idx;
+            switch (fd.cnst) {
+            case 1: idx = s.re > 0; break;
+            case 2: idx = 2 * (s.im > 0) + (s.re > 0); break;
+            case 3: idx = (fabsf(s.re) <= fabsf(s.im) ? 4u : 0u) | (s.re <= 0 ? 1u : 0u) | (s.im <= 0 ? 2u : 0u); break;
+            default: { const float level = sqrtf(0.1f);
+                idx = (s.im > 0 ? 8u : 0u) | (s.re < 0 ? 4u : 0u) | (fabsf(s.re) > 2 * level ? 2u : 0u) | (fabsf(s.im) > 2 * level ? 1u : 0u); } break;
+            }
+            v |= ((idx >> jb) & 1u) << j;
+        }
+        bytes[b] = uint8_t(v);
     }
     __syncthreads();
-    if (fd.n_syms <= 0) return; // payload == 0: frame dropped after the equaliser (:218,254)
-
-    // ofdm_serializer_vcc (symbols_skipped = 1) + soft / hard demapper
-    const int bps = fd.cnst == 4 ? 4 : fd.cnst; // 1,2,3,4
-    const float npwr = float(sqrt(s_stat.noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
-    const double neg_inv_npwr = -1.0 / double(npwr);
-    uint8_t* hard_syms = reinterpret_cast<uint8_t*>(buf); // no-FEC: symbol values (<= N*8 bytes available)
-    auto demap_one = [&](int q, int i, int r, int set) {
-        const cf32 s = frame[i * N + t.occ_idx[set * t.max_occ + r]];
-        if (soft_syms) soft_syms[size_t(blockIdx.x) * t.frame_capacity + q] = s;
-        if (t.has_fec) {
-            float* o = llr_out + size_t(llr_off[blockIdx.x]) + size_t(q) * bps;
-            if (t.llr_dist_mode) {
-                switch (bps) {
-                case 1: soft_demap_symbol<1, true>(s, pts, neg_inv_npwr, o); break;
-                case 2: soft_demap_symbol<2, true>(s, pts, neg_inv_npwr, o); break;
-                case 3: soft_demap_symbol<3, true>(s, pts, neg_inv_npwr, o); break;
-                default: soft_demap_symbol<4, true>(s, pts, neg_inv_npwr, o); break;
-                }
-            } else {
-                switch (bps) {
-                case 1: soft_demap_symbol<1, false>(s, pts, neg_inv_npwr, o); break;
-                case 2: soft_demap_symbol<2, false>(s, pts, neg_inv_npwr, o); break;
-                case 3: soft_demap_symbol<3, false>(s, pts, neg_inv_npwr, o); break;
-                default: soft_demap_symbol<4, false>(s, pts, neg_inv_npwr, o); break;
-                }
-            }
+    if (tid == 0) {
+        int ok = 0;
+        if (n_written >= 4) {
+            const uint32_t crc = crc_bits(bytes, n_written - 4, 32, 0x04C11DB7u, 0xFFFFFFFFu, 0xFFFFFFFFu, true, true);
+            ok = 1;
+            for (int i = 0; i < 4; i++) if (bytes[n_written - 4 + i] != ((crc >> (8 * i)) & 0xFF)) ok = 0;
         }
-    };
-    if (t.n_occ_sets == 1) {
-        // one carrier set: symbol q sits on carrier (q mod nocc) of OFDM symbol (q div nocc); all lanes busy
-        const int nocc = t.occ_len[0];
-        for (int q = tid; q < fd.n_syms; q += blockDim.x) {
-            const int i = q / nocc;
-            if (i < L) demap_one(q, i, q - i * nocc, 0);
-        }
-    } else {
-        int q_base = 0;
-        for (int i = 0; i < L && q_base < fd.n_syms; i++) {
-            const int set = (1 + i) % t.n_occ_sets;
-            const int nocc = t.occ_len[set];
-            for (int r = tid; r < nocc; r += blockDim.x)
-                if (q_base + r < fd.n_syms) demap_one(q_base + r, i, r, set);
-            q_base += nocc;
-        }
-    }
-    if (!t.has_fec) {
-        // no-FEC tail: ofdm_adaptive_constellation_decoder_cb + ofdm_adaptive_frame_pack_bb; the soft
-        // symbols are sliced with the same decision makers, repacked bps -> 8 LSB first, CRC-32 checked.
-        // (buf holds at most N*8 bytes: frames of up to N*8 symbols are sliced in one pass.)
-        __syncthreads();
-        uint8_t* bytes = nofec_bytes + size_t(blockIdx.x) * nofec_stride;
-        const int n_bits = fd.n_syms * bps;
-        int n_written = n_bits / 8 + ((n_bits % 8) ? 1 : 0);
-        if (n_bits % 8) --n_written;
-        for (int b = tid; b < n_written; b += blockDim.x) {
-            unsigned v = 0;
-            for (int j = 0; j < 8; j++) {
-                const int bit = b * 8 + j, q = bit / bps, jb = bit % bps;
-                // locate symbol q: data carriers per OFDM symbol may differ per set
-                int i = 0, base = 0;
-                while (true) { const int nocc = t.occ_len[(1 + i) % t.n_occ_sets]; if (q < base + nocc) break; base += nocc; i++; }
-                const int set = (1 + i) % t.n_occ_sets;
-                const cf32 s = frame[i * N + t.occ_idx[set * t.max_occ + (q - base)]];
-                unsigned idx;
-                switch (fd.cnst) {
-                case 1: idx = s.re > 0; break;
-                case 2: idx = 2 * (s.im > 0) + (s.re > 0); break;
-                case 3: idx = (fabsf(s.re) <= fabsf(s.im) ? 4u : 0u) | (s.re <= 0 ? 1u : 0u) | (s.im <= 0 ? 2u : 0u); break;
-                default: { const float level = sqrtf(0.1f);
-                    idx = (s.im > 0 ? 8u : 0u) | (s.re < 0 ? 4u : 0u) | (fabsf(s.re) > 2 * level ? 2u : 0u) | (fabsf(s.im) > 2 * level ? 1u : 0u); } break;
-                }
-                v |= ((idx >> jb) & 1u) << j;
-            }
-            bytes[b] = uint8_t(v);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int ok = 0;
-            if (n_written >= 4) {
-                const uint32_t crc = crc_bits(bytes, n_written - 4, 32, 0x04C11DB7u, 0xFFFFFFFFu, 0xFFFFFFFFu, true, true);
-                ok = 1;
-                for (int i = 0; i < 4; i++) if (bytes[n_written - 4 + i] != ((crc >> (8 * i)) & 0xFF)) ok = 0;
-            }
-            nofec_info[2 * blockIdx.x] = ok;
-            nofec_info[2 * blockIdx.x + 1] = n_written;
-        }
-        (void)hard_syms;
+        nofec_info[2 * blockIdx.x] = ok;
+        nofec_info[2 * blockIdx.x + 1] = n_written;
     }
 }
 
@@ -1142,28 +1141,32 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
 
 size_t payload_lds_bytes(const RxTables& t)
 {
-    size_t b = size_t(4 * t.fft_len) * sizeof(cf32) + size_t(t.frame_length) * t.fft_len * sizeof(cf32) +
-               size_t((t.fft_len + 63) / 64) * sizeof(Welford) + size_t(t.fft_len / 2) * sizeof(cf32);
+    size_t b = size_t(4 * t.fft_len) * sizeof(cf32) + size_t((t.fft_len + 63) / 64) * sizeof(Welford) +
+               size_t(t.fft_len / 2) * sizeof(cf32);
     return (b + 15) & ~size_t(15);
 }
 
+// phase B: frame equaliser (FFT + decision-directed one-tap equaliser + SNR estimate) -> soft demapper (FEC) or
+// hard demapper + packer + CRC (no FEC); the equalised data symbols are handed over in `soft_syms` (n_frames x capacity)
 int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
                    const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
                    const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms,
                    uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st)
 {
     if (n_frames <= 0) return DTL_OK;
+    if (!soft_syms) { set_last_error("payload: no buffer for the equalised symbols"); return DTL_ERR_INVALID_ARG; }
     const size_t lds = payload_lds_bytes(t);
-    if (lds > 159 * 1024) { set_last_error("payload kernel: frame does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
-    static size_t attr_lds = 64 * 1024;
-    if (lds > attr_lds) {
-        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(payload_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_lds = lds;
+    if (lds > 64 * 1024) { set_last_error("payload kernel: FFT scratch does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(frame_eq_kernel, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
+                       stats, eq_hard, eq_soft, soft_syms);
+    if (t.has_fec) {
+        const dim3 grid(n_frames, (t.frame_capacity + 255) / 256);
+        if (t.llr_dist_mode) hipLaunchKernelGGL(demap_kernel<true>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
+        else hipLaunchKernelGGL(demap_kernel<false>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
+    } else {
+        hipLaunchKernelGGL(nofec_tail_kernel, dim3(n_frames), dim3(256), 0, st, t, frames, soft_syms, nofec_bytes, nofec_info,
+                           nofec_stride);
     }
-    hipLaunchKernelGGL(payload_kernel, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
-                       taps, stats, llr_off, llr, eq_hard, eq_soft, soft_syms, nofec_bytes, nofec_info,
-                       nofec_stride);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

@@ -384,11 +384,15 @@ int Receiver::init()
         set_last_error("Length of sync sequence(s) must be FFT length."); // ofdm_receiver.py:52-54
         return DTL_ERR_INVALID_ARG;
     }
-    for (auto& set : cfg.occupied_carriers)
+    for (auto& set : cfg.occupied_carriers) {
+        std::vector<uint8_t> seen(size_t(N), 0);
         for (int c : set) {
             int idx = c < 0 ? c + N : c;
             if (idx < 0 || idx >= N) { set_last_error("data carrier index out of bounds"); return DTL_ERR_INVALID_ARG; }
+            if (seen[idx]) { set_last_error("data carrier listed twice in one set"); return DTL_ERR_INVALID_ARG; }
+            seen[idx] = 1;
         }
+    }
     const size_t np = cfg.pilot_carriers.empty() ? 0 : cfg.pilot_carriers[0].size();
     for (auto& set : cfg.pilot_carriers)
         if (set.size() != np) { set_last_error("pilot carrier sets must have equal size"); return DTL_ERR_INVALID_ARG; }
@@ -444,6 +448,7 @@ int Receiver::upload_tables()
     for (auto& s : cfg.occupied_carriers) max_occ = std::max<int>(max_occ, int(s.size()));
     std::vector<int16_t> occ_idx(size_t(n_occ_sets) * max_occ, 0), occ_len(n_occ_sets);
     std::vector<uint8_t> occupied(N, 0);
+    std::vector<int16_t> occ_rank(size_t(n_occ_sets) * N, -1);
     for (int s = 0; s < n_occ_sets; s++) {
         occ_len[s] = int16_t(cfg.occupied_carriers[s].size());
         for (size_t k = 0; k < cfg.occupied_carriers[s].size(); k++) {
@@ -451,6 +456,10 @@ int Receiver::upload_tables()
             occ_idx[size_t(s) * max_occ + k] = int16_t(idx);
             occupied[idx] = 1;
         }
+        // a carrier listed twice would be read by both serializer slots; the equaliser lane can write one of them
+        // (first listing wins here): such maps are rejected in init()
+        for (size_t k = cfg.occupied_carriers[s].size(); k-- > 0;)
+            occ_rank[size_t(s) * N + shifted(cfg.occupied_carriers[s][k])] = int16_t(k);
     }
     const int n_pilot_sets = int(cfg.pilot_carriers.size());
     const int n_pilots = n_pilot_sets ? int(cfg.pilot_carriers[0].size()) : 0;
@@ -500,6 +509,7 @@ int Receiver::upload_tables()
     const size_t o_tw = put(tw.data(), tw.size() * sizeof(cf32));
     const size_t o_br = put(br.data(), br.size() * 2);
     const size_t o_oi = put(occ_idx.data(), occ_idx.size() * 2);
+    const size_t o_ork = put(occ_rank.data(), occ_rank.size() * 2);
     const size_t o_ol = put(occ_len.data(), occ_len.size() * 2);
     const size_t o_oc = put(occupied.data(), occupied.size());
     const size_t o_pm = put(pmask.data(), pmask.size());
@@ -525,6 +535,7 @@ int Receiver::upload_tables()
     tab_.twiddle = reinterpret_cast<const cf32*>(b + o_tw);
     tab_.bitrev = reinterpret_cast<const uint16_t*>(b + o_br);
     tab_.occ_idx = reinterpret_cast<const int16_t*>(b + o_oi);
+    tab_.occ_rank = reinterpret_cast<const int16_t*>(b + o_ork);
     tab_.occ_len = reinterpret_cast<const int16_t*>(b + o_ol);
     tab_.occupied = b + o_oc;
     tab_.pilot_mask = b + o_pm;
@@ -907,11 +918,11 @@ int Receiver::stage_frames(Call& c)
         DTL_TRY(h_llr_off_.ensure(size_t(n_cand) * 4));
         if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_cand) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
         if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_cand) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
-        if (flags & RX_WANT_SOFT_SYMS) {
-            DTL_TRY(d_soft_syms.ensure(size_t(n_cand) * capacity_ * sizeof(cf32)));
-            DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_cand) * capacity_ * sizeof(cf32), st));
-            ss_out = d_soft_syms.as<cf32>();
-        }
+        // the equalised data symbols always cross HBM (frame equaliser -> demapper); the buffer is cleared only when
+        // the caller looks at it (positions behind a frame's last symbol)
+        DTL_TRY(d_soft_syms.ensure(size_t(n_cand) * capacity_ * sizeof(cf32)));
+        if (flags & RX_WANT_SOFT_SYMS) DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms.p, 0, size_t(n_cand) * capacity_ * sizeof(cf32), st));
+        ss_out = d_soft_syms.as<cf32>();
         if (!cfg.has_fec) {
             DTL_TRY(d_staging_.ensure(size_t(n_cand) * nofec_stride));
             DTL_TRY(d_nofec_info_.ensure(size_t(n_cand) * 8));
@@ -990,7 +1001,7 @@ int Receiver::stage_frames(Call& c)
             DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
                                    d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0, d_llr_off_.as<uint32_t>() + f0,
                                    d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
-                                   ss_out ? ss_out + size_t(f0) * capacity_ : nullptr,
+                                   ss_out + size_t(f0) * capacity_,
                                    nofec_bytes ? nofec_bytes + size_t(f0) * nofec_stride : nullptr,
                                    nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st));
         }

@@ -26,6 +26,7 @@ struct RxTables {
     const uint16_t* bitrev;    // fft_len
     const int16_t* occ_idx;    // n_occ_sets x max_occ : shifted positions of the data carriers
     const int16_t* occ_len;    // n_occ_sets
+    const int16_t* occ_rank;   // n_occ_sets x fft_len : index of the data carrier at a shifted position, -1 if none
     const uint8_t* occupied;   // fft_len : union of all data-carrier sets (shifted positions)
     const uint8_t* pilot_mask; // n_pilot_sets x fft_len
     const cf32* pilot_val;     // n_pilot_sym_sets x fft_len
