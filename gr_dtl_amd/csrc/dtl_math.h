@@ -54,6 +54,22 @@ __device__ __forceinline__ float dm_div_inrange(float a, float b)
     return __builtin_fmaf(r1, y1, q1);
 }
 
+// -a / b for many numerators a >= 0 and one divisor b whose correctly rounded reciprocal r = RN(1 / b) is known:
+// the quotient-refinement half of the IEEE division sequence (two residual corrections with fused multiply-adds),
+// which rounds correctly once the reciprocal is within an ulp -- here it is exact to half an ulp.  Anything that
+// is not an ordinary finite quotient takes the plain division.  Results in the subnormal range may differ in the
+// last bit, which the demapper cannot see (exp of both is exactly 1).  tools/math_check.hip compares with -a / b.
+__device__ __forceinline__ float dm_neg_div_by(float a, float b, float r)
+{
+    float q = a * r;
+    if (!(q < 3.0e38f) || !(b < 3.0e38f)) return -a / b;
+    float e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    return -q;
+}
+
 __device__ __forceinline__ float dm_log(float x0)
 {
     const bool tiny = x0 < 1.17549435e-38f;

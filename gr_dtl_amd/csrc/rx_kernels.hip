@@ -544,13 +544,13 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 // constellation::calc_soft_dec (exact MAP over all M points, accumulation in point order) followed by
 // the LSB-first reversal of soft_cf_impl.cc:146.  BPS is a compile-time constant so that the bit tests
 // of the accumulation vanish; the arithmetic per point (dist, -dist/npwr, exp, adds in point order) is
-// the reference's.  The single-precision quotient -dist/npwr is formed as float(double(dist) * (-1/npwr)):
-// the f64 product is within 2^-52 of the exact quotient while a quotient of two floats is never closer
-// than 2^-49 (relative) to a rounding boundary of the float format, so the result IS the correctly
-// rounded IEEE quotient (3 full-rate instructions instead of the ~11 of v_div_scale/rcp/fma/fixup);
+// the reference's.  The single-precision quotient -dist/npwr has one divisor per frame: its correctly rounded
+// reciprocal is formed once (float(1 / double(npwr)): a quotient of two floats is never closer than 2^-49
+// relative to a rounding boundary, the f64 quotient is within 2^-53) and every quotient takes the refinement
+// half of the IEEE division sequence (dm_neg_div_by: 1 multiply + 4 FMAs instead of ~11 instructions);
 // quotients in the subnormal range all map to exp() == 1.  tools/math_check.hip checks both claims.
 template <int BPS, bool PLAIN_DIST>
-__device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, double neg_inv_npwr,
+__device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, float npwr, float rinv,
                                                   float* __restrict__ o)
 {
     constexpr int M = 1 << BPS;
@@ -583,7 +583,7 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
         }
         // compile-time switch: a runtime select would evaluate the correctly rounded sqrtf for every point
         const float dist = PLAIN_DIST ? sqrtf(sq) : sq;
-        const float d = dm_exp(float(double(dist) * neg_inv_npwr)); // fixed-sequence expf (dtl_math.h)
+        const float d = dm_exp(dm_neg_div_by(dist, npwr, rinv)); // -dist / npwr exactly; fixed-sequence expf (dtl_math.h)
 #pragma unroll
         for (int j = 0; j < BPS; j++) {
             if ((m >> j) & 1) p1[j] += d;
@@ -749,14 +749,14 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     const int bps = cnst == 4 ? 4 : cnst;
     const cf32* pts = t.cnst_pts + cnst * 16;
     const float npwr = float(sqrt(stats[f].noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
-    const double neg_inv_npwr = -1.0 / double(npwr);
+    const float rinv = float(1.0 / double(npwr));        // the correctly rounded single reciprocal
     const cf32 s = soft_syms[size_t(f) * t.frame_capacity + q];
     float* o = llr_out + size_t(llr_off[f]) + size_t(q) * bps;
     switch (bps) {
-    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
-    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
-    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
-    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts, neg_inv_npwr, o); break;
+    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
+    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
+    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
+    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
     }
 }
 
@@ -899,17 +899,17 @@ struct CnstPoints {
 // ofdm_adaptive_constellation_soft_cf (soft_cf_impl.cc:89-148): bps soft bits per symbol, LSB first
 template <bool PLAIN_DIST>
 __global__ __launch_bounds__(256) void soft_demap_kernel(const cf32* __restrict__ syms, int64_t n, int bps, CnstPoints pts,
-                                                        double neg_inv_npwr, float* __restrict__ llr)
+                                                        float npwr, float rinv, float* __restrict__ llr)
 {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float* o = llr + i * bps;
     const cf32 s = syms[i];
     switch (bps) {
-    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
-    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
-    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
-    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts.p, neg_inv_npwr, o); break;
+    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
+    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
+    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
+    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
     }
 }
 
@@ -1269,10 +1269,10 @@ int launch_soft_demap(const cf32* syms, int64_t n, int cnst, double noise, int d
     // soft_cf_impl.cc:89-103: sigma = sqrt(noise), or 0.001 when no estimate is available
     double sigma = 0.001;
     if (noise >= 0) sigma = std::sqrt(noise);
-    const double neg_inv_npwr = -1.0 / double(float(sigma));
+    const float npwr = float(sigma), rinv = float(1.0 / double(npwr));
     const int64_t grid = (n + 255) / 256;
-    if (dist_mode) hipLaunchKernelGGL(soft_demap_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, neg_inv_npwr, llr);
-    else hipLaunchKernelGGL(soft_demap_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, neg_inv_npwr, llr);
+    if (dist_mode) hipLaunchKernelGGL(soft_demap_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, npwr, rinv, llr);
+    else hipLaunchKernelGGL(soft_demap_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, npwr, rinv, llr);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

@@ -100,6 +100,8 @@ __global__ void check_div(unsigned long long* mism, unsigned long long* total, u
             if ((ia & 15) == 15) ma = unsigned(rng()) & 0xffu;
             const float a = __int_as_float(int((ea << 23) | ma));
             const float q0 = -a / b, q1 = float(double(a) * ninv);
+            const float q2 = dtl::dm_neg_div_by(a, b, float(1.0 / double(b)));
+            if (!(fabsf(q0) < 1.17549435e-38f) && __float_as_int(q0) != __float_as_int(q2)) { bad++; example[0] = unsigned(__float_as_int(a)); example[1] = unsigned(__float_as_int(b)); }
             cnt++;
             const bool tiny = fabsf(q0) < 1.17549435e-38f;
             // subnormal quotients may differ (double rounding) but exp() of both is exactly 1
@@ -134,7 +136,7 @@ int main()
     hipLaunchKernelGGL(check_div, dim3(8192), dim3(256), 0, 0, d2, d2 + 1, ex2);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h2, d2, 16, hipMemcpyDeviceToHost); (void)hipMemcpy(hex2, ex2, 8, hipMemcpyDeviceToHost);
-    printf("float(double(a) * (-1/b)) vs -a/b: %llu mismatches over %llu operand pairs (example a=0x%08x b=0x%08x)\n",
+    printf("float(double(a) * (-1/b)) and the two-correction f32 form vs -a/b: %llu mismatches over %llu operand pairs (example a=0x%08x b=0x%08x)\n",
            h2[0], h2[1], hex2[0], hex2[1]);
     return (h != 0) || (h2[0] != 0) || (hl != 0);
 }
