@@ -183,6 +183,9 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            # results stay where the C ABI leaves them (payload bytes in HBM, per-frame / per-block records in the
+            # handle's host memory); the numpy copies of the records are made on first read (after the timed region)
+            res = None
             res = rx.work(x, copy_outputs=False)
             ldpc_ms.append(res.stage_ms[6])
             payload_ms.append(res.stage_ms[7])
@@ -200,6 +203,7 @@ def main():
             torch.cuda.set_device(device)
             with torch.cuda.stream(streams[i]):
                 for _ in range(count):
+                    r = last[i] = None
                     r = rxs[i].work(x, copy_outputs=False)
                     last[i] = r
                     ldpc_ms.append(r.stage_ms[6])

@@ -8,6 +8,7 @@ the streams the reference hier block exposes on its output ports.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -120,25 +121,51 @@ _FRAME_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4", C.c_double: "<
 _TB_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4"}[t]) for n, t in TbInfo._fields_], align=True)
 
 
+_RECORD_FIELDS = ("frames", "tbs", "raw_triggers", "fixed_triggers", "sc_freq")
+
+
+def _records(ptr, count, dtype):
+    # one memmove (a structured-dtype .copy() goes field by field and costs milliseconds)
+    arr = np.empty(count, dtype=dtype)
+    if count:
+        C.memmove(arr.ctypes.data, ptr, count * arr.itemsize)
+    return arr
+
+
 class rx_result:
     """Outputs of one ``work`` call.  Port numbering follows ofdm_receiver (ofdm_receiver.py:18-20):
     out0 ``payload`` (bytes), out1/out2 trigger positions (fixed / raw), out3 ``eq_hard``,
     out4 ``soft_syms``, out5 ``sc_freq`` (held angle per raw trigger); message ports ``monitor`` /
-    ``feedback`` / ``header`` become the per-frame / per-TB record arrays."""
+    ``feedback`` / ``header`` become the per-frame / per-TB record arrays.
+
+    The record arrays (``frames``, ``tbs``, ``raw_triggers``, ``fixed_triggers``, ``sc_freq``) live in host
+    memory owned by the C handle (include/dtl_rx.h: valid until the next call on it).  They are copied into
+    numpy arrays the first time one of them is read, or -- if this object is still alive then -- just before
+    the receiver starts its next call; a result nobody reads costs no copy (~9 MB per 64k-frame batch)."""
 
     def __init__(self):
         self.payload = None        # torch.uint8 (device)
-        self.frames = None         # numpy structured array, one row per visited trigger
-        self.tbs = None            # numpy structured array, one row per transport block
-        self.raw_triggers = None
-        self.fixed_triggers = None
-        self.sc_freq = None
+        self._pending = None       # name -> (pointer, count, dtype) of records still in the handle's memory
         self.eq_hard = self.eq_soft = self.soft_syms = self.llr = self.taps = self.hdr_bits = None
         self.metric = self.cw_bits = self.cw_nit = None
         self.stage_ms = None
         self.n_payload_frames = 0
         self.n_payload_bytes = 0
         self.n_codewords = 0
+
+    def _materialise(self):
+        pending, self._pending = self._pending, None
+        if pending:
+            for name, (ptr, count, dtype) in pending.items():
+                self.__dict__[name] = _records(ptr, count, dtype)
+
+    def __getattr__(self, name):   # only reached for attributes not in __dict__
+        if name in _RECORD_FIELDS:
+            # frames: numpy structured array, one row per visited trigger; tbs: one row per transport block
+            self._materialise()
+            if name in self.__dict__:
+                return self.__dict__[name]
+        raise AttributeError(name)
 
     def payload_bytes(self):
         return self.payload.cpu().numpy()
@@ -178,6 +205,7 @@ class ofdm_receiver:
         self.sync_words = [config.sync_word1, config.sync_word2]
         self._config = config
         self._h = C.c_void_p()
+        self._last_result = None
         self._setup()
 
     # -- construction -------------------------------------------------------------------------
@@ -208,6 +236,7 @@ class ofdm_receiver:
 
     def __del__(self):
         try:
+            self._settle_last_result()
             if self._h:
                 _lib.lib().dtl_rx_destroy(self._h)
         except Exception:
@@ -231,7 +260,16 @@ class ofdm_receiver:
         return self._run(iq, want, copy_outputs, bool(final))
 
     def reset(self):
+        self._settle_last_result()
         _lib.lib().dtl_rx_reset(self._h)
+
+    def _settle_last_result(self):
+        """The previous result's records still sit in the handle's buffers, which the next call overwrites: copy
+        them out now if somebody still holds that result."""
+        last = self._last_result() if self._last_result is not None else None
+        self._last_result = None
+        if last is not None:
+            last._materialise()
 
     @property
     def stream_position(self):
@@ -249,6 +287,7 @@ class ofdm_receiver:
             flags |= WANT.get(w, 0)
         res = _Result()
         st = _lib.current_stream_ptr()
+        self._settle_last_result()
         if final is None:
             _lib.check(_lib.lib().dtl_rx_process(self._h, iq.data_ptr(), iq.numel(), flags, st, C.byref(res)))
         else:
@@ -259,18 +298,11 @@ class ofdm_receiver:
         out.n_codewords = int(res.n_codewords)
         out.stage_ms = list(res.stage_ms)
         nf, nt = int(res.n_frames), int(res.n_tbs)
-        def records(ptr, count, dtype):
-            # one memmove (a structured-dtype .copy() goes field by field and costs milliseconds)
-            arr = np.empty(count, dtype=dtype)
-            if count:
-                C.memmove(arr.ctypes.data, ptr, count * arr.itemsize)
-            return arr
-        out.frames = records(res.frames, nf, _FRAME_DTYPE)
-        out.tbs = records(res.tbs, nt, _TB_DTYPE)
         nr, nx = int(res.n_raw_triggers), int(res.n_fixed_triggers)
-        out.raw_triggers = records(res.raw_triggers, nr, np.int64)
-        out.fixed_triggers = records(res.fixed_triggers, nx, np.int64)
-        out.sc_freq = records(res.trigger_angles, nr, np.float32)
+        out._pending = {"frames": (res.frames, nf, _FRAME_DTYPE), "tbs": (res.tbs, nt, _TB_DTYPE),
+                        "raw_triggers": (res.raw_triggers, nr, np.int64), "fixed_triggers": (res.fixed_triggers, nx, np.int64),
+                        "sc_freq": (res.trigger_angles, nr, np.float32)}
+        self._last_result = weakref.ref(out)
         out.n_payload_bytes = int(res.n_payload_bytes)
         if not copy_outputs:
             return out
