@@ -360,7 +360,11 @@ struct Receiver::StreamState {
 
 Receiver::Receiver() : ss_(std::make_unique<StreamState>()) {}
 
-void Receiver::reset_stream() { ss_ = std::make_unique<StreamState>(); }
+void Receiver::reset_stream()
+{
+    if (side_) (void)hipStreamSynchronize(side_); // a failed call may leave trigger-angle work in flight
+    ss_ = std::make_unique<StreamState>();
+}
 
 int64_t Receiver::stream_position() const { return ss_->next_abs; }
 
@@ -371,6 +375,8 @@ Receiver::~Receiver()
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto& e : chunk_ev_) if (e) (void)hipEventDestroy(e);
     if (ev_stats_) (void)hipEventDestroy(ev_stats_);
+    for (auto& e : angle_ev_) if (e) (void)hipEventDestroy(e);
+    if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
 }
 
 int Receiver::init()
@@ -640,6 +646,11 @@ struct Receiver::Call {
     std::vector<int32_t> nofec_info;
     std::vector<TbResult> tb_res;
     uint32_t total_bytes = 0;
+    // arg(P) at the raw triggers, submitted group by group as the plateau detector produces them
+    struct AnglePart { size_t first, count; };
+    std::vector<AnglePart> angle_parts;
+    size_t angle_parts_done = 0;  // groups whose angles are on the host and whose oscillator segments are complete
+    size_t first_new_seg = 0;     // ss.segs index of this call's first trigger
     void lap(const char* what)
     {
         if (!dbg) return;
@@ -694,6 +705,8 @@ int Receiver::stream_begin(Call& c)
 int Receiver::stage_sync(Call& c)
 {
     RX_CALL_LOCALS(c);
+    Call& c_ = c; // the range loops below use `c` as their index
+    c.first_new_seg = ss.segs.size();
     // ---- K1: timing metric -> threshold crossings -> plateau detector (host), pipelined over up to four
     // sample ranges: the crossings of one range are sorted and run through the (incremental) plateau
     // detector while the sync kernel works on the next range.
@@ -762,13 +775,24 @@ int Receiver::stage_sync(Call& c)
                 if (A) for (auto& e : edges) e += static_cast<unsigned long long>(A) << 1; // buffer-relative -> absolute
                 const bool last = c + 1 == rg.size();
                 std::vector<int64_t> trig = plateau_stream(ss.edge_carry, edges, ss.plateau_i, A + r.me, cp, final && last, &produced);
+                const size_t first = raw_triggers.size();
                 raw_triggers.insert(raw_triggers.end(), trig.begin(), trig.end());
                 plateau_ms += now_ms() - t_e;
                 n_edges_total += n_edges;
+                // K1b for this range's triggers on the side stream (the working buffer is complete: the event just
+                // waited for sits behind its copies), then the oscillator segments of the range before it
+                if (!side_) {
+                    int least = 0, greatest = 0;
+                    DTL_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    DTL_HIP_CHECK(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, greatest));
+                }
+                DTL_TRY(submit_angles(c_, first, trig.size(), side_));
+                if (!last && c_.angle_parts.size() > 1) DTL_TRY(collect_angles(c_, c_.angle_parts.size() - 1));
             }
         } else {
             // no new samples (a final flush): close what is open
             raw_triggers = plateau_stream(ss.edge_carry, {}, ss.plateau_i, E, cp, final, &produced);
+            DTL_TRY(submit_angles(c_, 0, raw_triggers.size(), st));
         }
     }
     dbg_n_edges = n_edges_total;
@@ -778,33 +802,88 @@ int Receiver::stage_sync(Call& c)
     return DTL_OK;
 }
 
+// K1b for raw_triggers[first, first + count): positions up, arg(P) kernel, angles down -- all on `on`, closed by
+// an event; the oscillator segments (sample_and_hold + frequency_modulator_fc) are opened here and completed by
+// collect_angles once the angles are on the host
+int Receiver::submit_angles(Call& c, size_t first, size_t count, hipStream_t on)
+{
+    StreamState& ss = *ss_;
+    ss.segs.reserve(ss.segs.size() + count);
+    for (size_t j = 0; j < count; j++) {
+        CfoSegment sg{};
+        sg.start = raw_triggers[first + j];
+        ss.segs.push_back(sg);
+    }
+    trigger_angles.resize(first + count, 0.0f);
+    if (!count) return DTL_OK;
+    const size_t need = first + count;
+    if (need * 8 > h_trig_.cap || need * 8 > d_trig_.cap || need * 4 > d_angle_.cap || need * 4 > h_angle_.cap) {
+        // growing the buffers discards them: take what is in flight first
+        DTL_TRY(collect_angles(c, c.angle_parts.size()));
+        const size_t want = std::max<size_t>(2 * need, size_t(2 * (c.W / frame_samples() + 1) + 1024));
+        DTL_TRY(h_trig_.ensure(want * 8));
+        DTL_TRY(d_trig_.ensure(want * 8));
+        DTL_TRY(d_angle_.ensure(want * 4));
+        DTL_TRY(h_angle_.ensure(want * 4));
+    }
+    int64_t* rel = h_trig_.as<int64_t>() + first;
+    for (size_t j = 0; j < count; j++) rel[j] = raw_triggers[first + j] - c.A;
+    DTL_HIP_CHECK(hipMemcpyAsync(d_trig_.as<int64_t>() + first, rel, count * 8, hipMemcpyHostToDevice, on));
+    DTL_TRY(launch_trigger_angle(c.iq, c.W, c.N, d_trig_.as<int64_t>() + first, int(count), d_angle_.as<float>() + first, on));
+    DTL_HIP_CHECK(hipMemcpyAsync(h_angle_.as<float>() + first, d_angle_.as<float>() + first, count * 4, hipMemcpyDeviceToHost, on));
+    const size_t part = c.angle_parts.size();
+    while (angle_ev_.size() <= part) {
+        hipEvent_t e = nullptr;
+        DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        angle_ev_.push_back(e);
+    }
+    DTL_HIP_CHECK(hipEventRecord(angle_ev_[part], on));
+    c.angle_parts.push_back({ first, count });
+    return DTL_OK;
+}
+
+// wait for the first `parts` groups and finish their oscillator segments (in order: each segment starts with the
+// previous segment's phase advanced to the new trigger; before the first trigger the held angle is 0 and the
+// phase stays 0)
+int Receiver::collect_angles(Call& c, size_t parts)
+{
+    StreamState& ss = *ss_;
+    const float sens = float(-2.0 / c.N);
+    for (; c.angle_parts_done < parts; c.angle_parts_done++) {
+        const Call::AnglePart& ap = c.angle_parts[c.angle_parts_done];
+        DTL_HIP_CHECK(hipEventSynchronize(angle_ev_[c.angle_parts_done]));
+        std::memcpy(trigger_angles.data() + ap.first, h_angle_.as<float>() + ap.first, ap.count * 4);
+        for (size_t j = ap.first; j < ap.first + ap.count; j++) {
+            CfoSegment& sg = ss.segs[c.first_new_seg + j];
+            sg.angle = trigger_angles[j];
+            sg.phase0 = 0.0;
+            if (c.first_new_seg + j > 0) {
+                const CfoSegment& pv = ss.segs[c.first_new_seg + j - 1];
+                double phase = pv.phase0 + double(sens * pv.angle) * double(sg.start - pv.start);
+                // fmod(phase + pi, 2 pi): for the usual argument in [0, 4 pi) the remainder is the argument itself
+                // or one exact subtraction (Sterbenz), i.e. what fmod returns, without its division loop
+                const double x = phase + M_PI, two_pi = 2.0 * M_PI;
+                if (x >= 0.0 && x < two_pi) phase = x;
+                else if (x >= two_pi && x < 2.0 * two_pi) phase = x - two_pi;
+                else phase = std::fmod(x, two_pi);
+                if (phase < 0) phase += 2.0 * M_PI;
+                phase -= M_PI;
+                sg.phase0 = phase;
+            }
+        }
+    }
+    return DTL_OK;
+}
+
 // K1b + frame_detect_bb + candidate list
 int Receiver::stage_triggers(Call& c)
 {
     RX_CALL_LOCALS(c);
-    // ---- K1b: arg(P) at the raw triggers; oscillator segments (sample_and_hold + frequency_modulator_fc)
+    // ---- K1b (arg(P) at the raw triggers) was submitted range by range in stage_sync; frame_detect_bb and the
+    // candidate list only need the trigger POSITIONS and run while the last group is in flight
     n_raw = int(raw_triggers.size());
-    trigger_angles.assign(n_raw, 0.0f);
-    if (n_raw) {
-        std::vector<int64_t> rel(raw_triggers);
-        for (auto& t : rel) t -= A;
-        DTL_TRY(d_angle_.ensure(size_t(n_raw) * 4));
-        DTL_TRY(h_angle_.ensure(size_t(n_raw) * 4));
-        DTL_TRY(upload_vec(h_trig_, d_trig_, rel, st));
-        DTL_TRY(launch_trigger_angle(iq, W, N, d_trig_.as<int64_t>(), n_raw, d_angle_.as<float>(), st));
-        DTL_HIP_CHECK(hipMemcpyAsync(h_angle_.p, d_angle_.p, size_t(n_raw) * 4, hipMemcpyDeviceToHost, st));
-        // the angles are collected further down: frame_detect_bb and the candidate list only need the trigger
-        // POSITIONS and run on the host while the kernel and the copy are in flight
-    }
-    const size_t first_new_seg = ss.segs.size();
-    ss.segs.reserve(ss.segs.size() + n_raw);
-    for (int j = 0; j < n_raw; j++) {
-        CfoSegment sg{};
-        sg.start = raw_triggers[j];
-        ss.segs.push_back(sg);
-    }
     n_segs = int(ss.segs.size());
-    lap("angle launch + segs");
+    lap("sync ranges");
     // ---- frame_detect_bb (optional): one work() buffer = the trigger stream produced by this call
     std::vector<int64_t> new_fixed;
     if (cfg.use_sync_correct) {
@@ -844,32 +923,7 @@ int Receiver::stage_triggers(Call& c)
     }
     n_cand = int(cands.size());
     lap("candidates");
-    if (n_raw) {
-        DTL_HIP_CHECK(hipStreamSynchronize(st));
-        lap("angle wait");
-        std::memcpy(trigger_angles.data(), h_angle_.p, size_t(n_raw) * 4);
-        // the phase a segment starts with is the previous segment's phase advanced to the new trigger
-        // (before the first trigger the held angle is 0 and the phase stays 0)
-        const float sens = float(-2.0 / N);
-        for (int j = 0; j < n_raw; j++) {
-            CfoSegment& sg = ss.segs[first_new_seg + j];
-            sg.angle = trigger_angles[j];
-            sg.phase0 = 0.0;
-            if (first_new_seg + j > 0) {
-                const CfoSegment& pv = ss.segs[first_new_seg + j - 1];
-                double phase = pv.phase0 + double(sens * pv.angle) * double(sg.start - pv.start);
-                // fmod(phase + pi, 2 pi): for the usual argument in [0, 4 pi) the remainder is the argument itself
-                // or one exact subtraction (Sterbenz), i.e. what fmod returns, without its division loop
-                const double x = phase + M_PI, two_pi = 2.0 * M_PI;
-                if (x >= 0.0 && x < two_pi) phase = x;
-                else if (x >= two_pi && x < 2.0 * two_pi) phase = x - two_pi;
-                else phase = std::fmod(x, two_pi);
-                if (phase < 0) phase += 2.0 * M_PI;
-                phase -= M_PI;
-                sg.phase0 = phase;
-            }
-        }
-    }
+    DTL_TRY(collect_angles(c, c.angle_parts.size()));
     lap("segment phases");
     stage_ms[1] = now_ms() - t0; t0 = now_ms();
 

@@ -141,6 +141,8 @@ private:
     int stream_begin(Call& c);
     int stage_sync(Call& c);
     int stage_triggers(Call& c);
+    int submit_angles(Call& c, size_t first, size_t count, hipStream_t on);
+    int collect_angles(Call& c, size_t parts);
     int stage_frames(Call& c);
     int stage_blocks(Call& c);
     int stage_records(Call& c);
@@ -159,6 +161,8 @@ private:
     DevBuf d_work_, d_carry_, d_llr_carry_;
     std::vector<hipEvent_t> chunk_ev_; // one per candidate chunk of the phase A/B pipeline
     hipEvent_t ev_stats_ = nullptr;    // the per-frame SNR estimates have reached the host
+    hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
+    std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers
 };
 
 } // namespace dtl
