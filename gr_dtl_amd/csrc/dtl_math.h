@@ -70,6 +70,20 @@ __device__ __forceinline__ float dm_neg_div_by(float a, float b, float r)
     return -q;
 }
 
+// a / n in double for a divisor whose correctly rounded reciprocal r = RN(1 / n) comes from a table (the sample
+// counts of the SNR estimator): same refinement, same result as the IEEE division for every finite quotient that
+// is not subnormal -- the estimator's operands (differences of values near 1, small integer counts) never are;
+// anything else takes the plain division.
+__device__ __forceinline__ double dm_div_by_count(double a, double n, double r)
+{
+    double q = a * r;
+    if (!(fabs(q) < 1.0e300) || (q != 0.0 && fabs(q) < 1.0e-290)) return a / n;
+    double e = __builtin_fma(-n, q, a);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-n, q, a);
+    return __builtin_fma(e, r, q);
+}
+
 __device__ __forceinline__ float dm_log(float x0)
 {
     const bool tiny = x0 < 1.17549435e-38f;

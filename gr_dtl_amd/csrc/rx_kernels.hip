@@ -35,23 +35,22 @@ __device__ __forceinline__ cf32 cscale(float s, cf32 a) { return { s * a.re, s *
 __device__ __forceinline__ cf32 cconj(cf32 a) { return { a.re, -a.im }; }
 __device__ __forceinline__ bool cnonzero(cf32 a) { return a.re != 0.0f || a.im != 0.0f; }
 
-// (a+ib)/(c+id), Smith's algorithm in float (libgcc __divsc3 for finite operands)
+// (a+ib)/(c+id), Smith's algorithm in float (libgcc __divsc3 for finite operands).  Its two cases
+//   |c| <  |d|:  r = c/d, den = c r + d, ((a r + b) / den, (b r - a) / den)
+//   |c| >= |d|:  r = d/c, den = d r + c, ((b r + a) / den, (b - a r) / den)
+// are one sequence of operations on swapped operands (only the last subtraction changes direction), so the lanes of
+// a wave -- which split between the cases at random -- share the three divisions instead of executing six.
 __device__ __forceinline__ cf32 cdiv(cf32 x, cf32 y)
 {
-    const float a = x.re, b = x.im, c = y.re, d = y.im;
-    cf32 q;
-    if (fabsf(c) < fabsf(d)) {
-        const float r = c / d;
-        const float den = (c * r) + d;
-        q.re = ((a * r) + b) / den;
-        q.im = ((b * r) - a) / den;
-    } else {
-        const float r = d / c;
-        const float den = (d * r) + c;
-        q.re = ((b * r) + a) / den;
-        q.im = (b - (a * r)) / den;
-    }
-    return q;
+    const bool sw = fabsf(y.re) < fabsf(y.im);
+    const float p = sw ? y.re : y.im, qd = sw ? y.im : y.re;
+    const float m = sw ? x.re : x.im, n = sw ? x.im : x.re;
+    const float r = p / qd;
+    const float den = (p * r) + qd;
+    const float re_num = (m * r) + n;
+    const float t = n * r;
+    const float im_num = sw ? (t - m) : (m - t);
+    return { re_num / den, im_num / den };
 }
 
 __device__ __forceinline__ cf32 expj(float phase)
@@ -110,7 +109,8 @@ __device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, 
 // elements {i, i+h, i+2h, i+3h} of one symbol, runs the two span-h butterflies of stage s and the two span-2h
 // butterflies of stage s+1 on them in registers (the same operations, in the same order per butterfly, as two
 // separate passes -- bit-identical), so the N/4 groups of four symbols keep all N lanes busy with half the
-// LDS traffic and half the barriers.  An odd last stage runs as a plain pass.  tw: N/2 twiddles in LDS.
+// LDS traffic and half the barriers.  An odd last stage runs as a plain pass.  tw: the N per-pass twiddles in LDS;
+// rows are stored LDS-swizzled (fft_lds_swizzle, rx_types.h): readers index them through it.
 __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
                                               int64_t trigger, int sym0, int n_sym, const CfoSegment* segs,
                                               int n_segs, const SegWindow& seg, cf32* buf, const cf32* tw)
@@ -118,59 +118,96 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
     const int N = t.fft_len, P = N + t.cp_len;
     const int tid = threadIdx.x;
     const float sens = float(-2.0 / N);
-    const int br = t.bitrev[tid];
-    for (int u = 0; u < n_sym; u++) {
-        // mixed[i] = r[i - (N+cp)] * osc[i]; symbol sample index i = trigger + sym*P + cp + tid
-        const int64_t i = trigger + int64_t(sym0 + u) * P + t.cp_len + tid;
-        const int64_t src = i - P;
-        cf32 v = { 0.0f, 0.0f };
-        if (src >= 0 && src < n_samples) v = iq[src];
-        buf[u * N + br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
-    }
-    __syncthreads();
     const int logN = __ffs(N) - 1;
     const int u = tid >> (logN - 2), q = tid & ((N >> 2) - 1); // symbol of the batch, group of four inside it
     cf32* x = buf + u * N;
     const bool active = u < n_sym;
+    // Up to N = 256 the N/4 lanes that transform one symbol sit in one wave.  Then the same lanes also load that
+    // symbol (four samples each), and between the load and the last butterfly pass nothing is shared across
+    // waves: those steps are ordered by the wave's own program order, and the workgroup meets only once, at the end.
+    const bool wave_local = (N >> 2) <= 64;
+    auto sync_stage = [&]() {
+        if (wave_local) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
+    // mixed[i] = r[i - (N+cp)] * osc[i]; sample s of symbol sym sits at stream index i = trigger + sym*P + cp + s
+    if (wave_local) {
+        if (active) {
+            const int64_t i0 = trigger + int64_t(sym0 + u) * P + t.cp_len;
+            cf32 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t src = i0 + (q + j * (N >> 2)) - P;
+                v[j] = cf32{ 0.0f, 0.0f };
+                if (src >= 0 && src < n_samples) v[j] = iq[src];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int sidx = q + j * (N >> 2);
+                x[t.bitrev[sidx]] = cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
+            }
+        }
+    } else {
+        const int br = t.bitrev[tid];                 // bit-reversed and swizzled
+        for (int uu = 0; uu < n_sym; uu++) {
+            const int64_t i = trigger + int64_t(sym0 + uu) * P + t.cp_len + tid;
+            const int64_t src = i - P;
+            cf32 v = { 0.0f, 0.0f };
+            if (src >= 0 && src < n_samples) v = iq[src];
+            buf[uu * N + br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
+        }
+    }
+    sync_stage();
     int st = 0;
     for (; st + 1 < logN; st += 2) {
         if (active) {
             const int h = 1 << st;
             const int k = q & (h - 1);
-            const int i0 = ((q >> st) << (st + 2)) + k, i1 = i0 + h, i2 = i1 + h, i3 = i2 + h;
+            // elements i0, i0 + h, i0 + 2h, i0 + 3h: bits st, st+1 of i0 are clear, so the swizzle of the sum is the
+            // XOR of the swizzles (the three offsets are wave-uniform)
+            const int i0 = fft_lds_swizzle(((q >> st) << (st + 2)) + k);
+            const int i1 = i0 ^ fft_lds_swizzle(h), i2 = i0 ^ fft_lds_swizzle(2 * h), i3 = i0 ^ fft_lds_swizzle(3 * h);
+            const cf32* twp = tw + (h - 1);
             // stage st: (i0,i1) and (i2,i3), twiddle W^(k N / 2h)
-            const cf32 w0 = tw[k << (logN - st - 1)];
+            const cf32 w0 = twp[k];
             cf32 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
             cf32 v = cmul_tw(a1, w0);
             a1 = csub(a0, v); a0 = cadd(a0, v);
             v = cmul_tw(a3, w0);
             a3 = csub(a2, v); a2 = cadd(a2, v);
             // stage st+1: (i0,i2) with W^(k N / 4h), (i1,i3) with W^((k+h) N / 4h)
-            const cf32 w1 = tw[k << (logN - st - 2)], w2 = tw[(k + h) << (logN - st - 2)];
+            const cf32 w1 = twp[h + k], w2 = twp[2 * h + k];
             v = cmul_tw(a2, w1);
             a2 = csub(a0, v); a0 = cadd(a0, v);
             v = cmul_tw(a3, w2);
             a3 = csub(a1, v); a1 = cadd(a1, v);
             x[i0] = a0; x[i1] = a1; x[i2] = a2; x[i3] = a3;
         }
-        __syncthreads();
+        sync_stage();
     }
     if (st < logN) { // log2(N) odd: one plain stage, N/2 butterflies per symbol = two per thread
         if (active) {
             const int half = 1 << st;
+            const cf32* twn = tw + (half - 1);        // the natural table W^k, k < N/2
             for (int r = 0; r < 2; r++) {
                 const int bt = q + r * (N >> 2);
                 const int grp = bt >> st, k = bt & (half - 1);
-                const int a = (grp << (st + 1)) + k, b = a + half;
-                const cf32 w = tw[k << (logN - st - 1)];
+                const int a = fft_lds_swizzle((grp << (st + 1)) + k), b = a ^ fft_lds_swizzle(half);
+                const cf32 w = twn[k];
                 const cf32 uu = x[a];
                 const cf32 vv = cmul_tw(x[b], w);
                 x[a] = cadd(uu, vv);
                 x[b] = csub(uu, vv);
             }
         }
-        __syncthreads();
+        sync_stage();
     }
+    if (wave_local) __syncthreads();                  // the rows are read across waves from here on
 }
 
 // CRC of a byte string, MSB-first register, optional reflection (gr::digital::crc semantics)
@@ -408,17 +445,17 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     cf32* H = Y + size_t(2 + h) * N;                        // N taps (shifted positions)
     float* gabs = reinterpret_cast<float*>(H + N);          // N/2+2 |B(g)| values
     uint8_t* bits = reinterpret_cast<uint8_t*>(gabs + N / 2 + 2); // hdr_bits
-    cf32* tw = reinterpret_cast<cf32*>(bits + ((t.hdr_bits + 15) & ~15)); // N/2 twiddles
-    cf32* terms = tw + N / 2;                                // n_g x (n_act + 1) products of the offset search
+    cf32* tw = reinterpret_cast<cf32*>(bits + ((t.hdr_bits + 15) & ~15)); // N per-pass twiddles
+    cf32* terms = tw + N;                                // n_g x (n_act + 1) products of the offset search
     __shared__ int s_off;
 
-    if (tid < N / 2) tw[tid] = t.twiddle[tid];
+    tw[tid] = t.twiddle[tid];
     const Candidate cd = cands[blockIdx.x];
     const SegWindow sw = seg_window(segs, n_segs, cd.seg);
     for (int s = 0; s < 2 + h; s += 4)
         load_and_fft4(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, sw, Y + size_t(s) * N, tw);
-    // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N]
-    auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + ((k + N / 2) & (N - 1))]; };
+    // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N] (rows are stored swizzled)
+    auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + fft_lds_swizzle((k + N / 2) & (N - 1))]; };
 
     // get_carr_offset: B(g) = sum_k conj(y1[k+g]) * conj(corr_v[k]) * y2[k+g], first maximum wins.
     // The reference adds the terms in carrier order in float, so the sum of one offset g is a serial chain;
@@ -598,12 +635,14 @@ struct Welford {
     double n, mean, m2;
 };
 
-__device__ __forceinline__ Welford welford_merge(Welford a, Welford b)
+// recip[k] = RN(1 / k): the counts are small integers, so their divisions take the table form (dm_div_by_count)
+__device__ __forceinline__ Welford welford_merge(Welford a, Welford b, const double* __restrict__ recip)
 {
     if (b.n == 0) return a;
     if (a.n == 0) return b;
     const double n = a.n + b.n, d = b.mean - a.mean;
-    return { n, a.mean + d * (b.n / n), a.m2 + b.m2 + d * d * (a.n * b.n / n) };
+    const double r = recip[int(n)];
+    return { n, a.mean + d * dm_div_by_count(b.n, n, r), a.m2 + b.m2 + d * d * dm_div_by_count(a.n * b.n, n, r) };
 }
 
 // Phase B is two kernels.  frame_eq_kernel needs barriers and LDS (FFT) but no more than four symbols of it:
@@ -628,8 +667,8 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
     const int N = t.fft_len, L = t.frame_length, tid = threadIdx.x, h = t.header_len;
     cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // 4 x N : FFT scratch (four symbols per batch)
     Welford* wred = reinterpret_cast<Welford*>(buf + 4 * N); // blockDim/64 partials
-    cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64); // N/2 twiddles
-    if (tid < N / 2) tw[tid] = t.twiddle[tid];
+    cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64); // N per-pass twiddles
+    tw[tid] = t.twiddle[tid];
 
     const FrameDesc fd = frames[blockIdx.x];
     const int off = fd.carr_offset;
@@ -641,12 +680,13 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
     int lag = 0, ks = k + off;
     if (ks >= N) { lag = 1; ks -= N; }
     else if (ks < 0) { lag = -1; ks += N; }
-    const int bin = (ks + N / 2) & (N - 1);           // natural-order FFT bin of the source column
+    const int bin = fft_lds_swizzle((ks + N / 2) & (N - 1)); // natural-order FFT bin of the source column, as stored
     cf32 Hk = taps_in[size_t(fd.cand) * N + k];
     const float alpha = t.eq_alpha;
     const bool occupied = t.occupied[k] != 0;
     const cf32* pts = t.cnst_pts + fd.cnst * 16;
     Welford w = { 0.0, 0.0, 0.0 };
+    const double* __restrict__ recip = t.recip_count;
     int pilot_carr_set = t.n_pilot_sets ? h % t.n_pilot_sets : 0;
     cf32* hard_row = eq_hard ? eq_hard + size_t(blockIdx.x) * total : nullptr;
     cf32* soft_row = eq_soft ? eq_soft + size_t(blockIdx.x) * total : nullptr;
@@ -670,7 +710,7 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
                 const double x = double(sqrtf(eqv.re * eqv.re + eqv.im * eqv.im));
                 w.n += 1.0;
                 const double d = x - w.mean;
-                w.mean += d / w.n;
+                w.mean += dm_div_by_count(d, w.n, recip[int(w.n)]);
                 w.m2 += d * (x - w.mean);
             } else {
                 unsigned idx;
@@ -720,13 +760,13 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
     // combine the per-carrier Welford states (Chan); double, fixed tree order
     for (int o = 32; o > 0; o >>= 1) {
         Welford other = { __shfl_down(w.n, o), __shfl_down(w.mean, o), __shfl_down(w.m2, o) };
-        w = welford_merge(w, other);
+        w = welford_merge(w, other, recip);
     }
     if ((tid & 63) == 0) wred[tid >> 6] = w;
     __syncthreads();
     if (tid == 0) {
         Welford a = wred[0];
-        for (int i = 1; i < int(blockDim.x + 63) / 64; i++) a = welford_merge(a, wred[i]);
+        for (int i = 1; i < int(blockDim.x + 63) / 64; i++) a = welford_merge(a, wred[i], recip);
         // mpsk_snr_est_simple::snr()/noise(); get_noise() (equalizer.cc:279-287)
         const double signal_db = 10.0 * log10(fabs(a.mean * a.mean));
         const double noise_db = 10.0 * log10(2.0 * a.m2 / a.n);
@@ -1117,7 +1157,7 @@ size_t header_lds_bytes(const RxTables& t)
 {
     size_t b = size_t(2 + t.header_len + 1) * t.fft_len * sizeof(cf32) + size_t(t.fft_len) * sizeof(cf32) +
                size_t(t.fft_len / 2 + 2) * sizeof(float) + size_t((t.hdr_bits + 15) & ~15) +
-               size_t(t.fft_len / 2) * sizeof(cf32) + (header_search_in_lds(t) ? header_search_bytes(t) : 0);
+               size_t(t.fft_len) * sizeof(cf32) + (header_search_in_lds(t) ? header_search_bytes(t) : 0);
     return (b + 15) & ~size_t(15);
 }
 
@@ -1142,7 +1182,7 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
 size_t payload_lds_bytes(const RxTables& t)
 {
     size_t b = size_t(4 * t.fft_len) * sizeof(cf32) + size_t((t.fft_len + 63) / 64) * sizeof(Welford) +
-               size_t(t.fft_len / 2) * sizeof(cf32);
+               size_t(t.fft_len) * sizeof(cf32);
     return (b + 15) & ~size_t(15);
 }
 

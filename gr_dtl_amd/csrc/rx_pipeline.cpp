@@ -436,18 +436,36 @@ int Receiver::upload_tables()
         if (bytes) std::memcpy(blob.data() + off, p, bytes);
         return off;
     };
-    std::vector<cf32> tw(N / 2);
+    std::vector<cf32> tw_nat(N / 2);
     for (int k = 0; k < N / 2; k++) {
         const double ang = -2.0 * M_PI * k / N;
-        tw[k] = { float(std::cos(ang)), float(std::sin(ang)) };
+        tw_nat[k] = { float(std::cos(ang)), float(std::sin(ang)) };
     }
-    std::vector<uint16_t> br(N);
     int logn = 0;
     while ((1 << logn) < N) logn++;
+    // The FFT of the receive kernels runs two butterfly stages per pass (load_and_fft4); pass `st` (h = 2^st) reads
+    // W^(k N/2h), W^(k N/4h), W^((k+h) N/4h) for k < h.  Stored contiguously per pass -- [2^st - 1 + k],
+    // [.. + h + k], [.. + 2h + k] -- consecutive lanes read consecutive entries (the natural table would be read
+    // with strides N/2h, N/4h: the same LDS banks).  An odd last stage reads the natural table, appended at 2^st - 1.
+    std::vector<cf32> tw(size_t(N), cf32{ 0.0f, 0.0f });
+    {
+        int st = 0;
+        for (; st + 1 < logn; st += 2) {
+            const int hh = 1 << st, base = hh - 1;
+            for (int k = 0; k < hh; k++) {
+                tw[base + k] = tw_nat[k << (logn - st - 1)];
+                tw[base + hh + k] = tw_nat[k << (logn - st - 2)];
+                tw[base + 2 * hh + k] = tw_nat[(k + hh) << (logn - st - 2)];
+            }
+        }
+        if (st < logn)
+            for (int k = 0; k < N / 2; k++) tw[(1 << st) - 1 + k] = tw_nat[k];
+    }
+    std::vector<uint16_t> br(N);
     for (int i = 0; i < N; i++) {
         int r = 0;
         for (int b = 0; b < logn; b++) if (i & (1 << b)) r |= 1 << (logn - 1 - b);
-        br[i] = uint16_t(r);
+        br[i] = uint16_t(fft_lds_swizzle(r));
     }
     const int n_occ_sets = int(cfg.occupied_carriers.size());
     int max_occ = 0;
@@ -526,6 +544,9 @@ int Receiver::upload_tables()
     const size_t o_sa = put(sync_act.data(), std::max<size_t>(sync_act.size(), 1) * 2);
     const size_t o_rf = put(ref.data(), ref.size() * sizeof(cf32));
     const size_t o_pt = put(pts.data(), pts.size() * sizeof(cf32));
+    std::vector<double> recip(size_t(cfg.frame_length) * N + 1, 0.0); // every pilot sample of a frame counted once
+    for (size_t k = 1; k < recip.size(); k++) recip[k] = 1.0 / double(k);
+    const size_t o_rc = put(recip.data(), recip.size() * sizeof(double));
     int rc = tab_blob_.ensure(blob.size());
     if (rc != DTL_OK) return rc;
     DTL_HIP_CHECK(hipMemcpy(tab_blob_.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -551,6 +572,7 @@ int Receiver::upload_tables()
     tab_.n_sync_act = int(sync_act.size());
     tab_.ref_sym = reinterpret_cast<const cf32*>(b + o_rf);
     tab_.cnst_pts = reinterpret_cast<const cf32*>(b + o_pt);
+    tab_.recip_count = reinterpret_cast<const double*>(b + o_rc);
     for (auto& d : decoders_)
         if (d && !d->uploaded()) { rc = d->upload(); if (rc != DTL_OK) return rc; }
     uploaded_ = true;

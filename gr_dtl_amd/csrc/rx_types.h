@@ -13,6 +13,16 @@ struct cf32 {
 constexpr int kMaxBps = 4;
 constexpr int kMaxHdrSyms = 4;
 
+// LDS placement of element e of one FFT row (8-byte elements, 16 per 128-byte bank row).  The butterfly passes
+// touch elements 4, 16, 64, ... apart and the bit-reversed load scatters consecutive lanes N/2, N/4, ... apart --
+// all multiples of the bank row, i.e. the same banks.  XOR-ing the position inside a bank row with a linear
+// function of the row number spreads every one of these access patterns (for 16 consecutive lanes) over all 16
+// positions; rows stay rows, so no padding is needed.  Linear: swz(a ^ b) == swz(a) ^ swz(b).
+__host__ __device__ inline int fft_lds_swizzle(int e)
+{
+    return e ^ (5 * ((e >> 4) & 3)) ^ ((e >> 6) & 3) ^ (((e >> 8) & 3) << 2);
+}
+
 // Read-only device tables derived from the configuration (one blob, see Receiver::upload_tables).
 struct RxTables {
     int fft_len, cp_len, frame_length, header_len, has_fec;
@@ -22,8 +32,8 @@ struct RxTables {
     int g_min, g_max;          // integer-CFO search range (even steps), ofdm_chanest_vcvc ctor
     float eq_alpha;
     int llr_dist_mode;
-    const cf32* twiddle;       // fft_len/2 : exp(-j 2 pi k / N)
-    const uint16_t* bitrev;    // fft_len
+    const cf32* twiddle;       // fft_len : exp(-j 2 pi k / N) regrouped per butterfly pass (see fft_pass_twiddles)
+    const uint16_t* bitrev;    // fft_len : bit-reversed index, already LDS-swizzled (fft_lds_swizzle)
     const int16_t* occ_idx;    // n_occ_sets x max_occ : shifted positions of the data carriers
     const int16_t* occ_len;    // n_occ_sets
     const int16_t* occ_rank;   // n_occ_sets x fft_len : index of the data carrier at a shifted position, -1 if none
@@ -35,6 +45,7 @@ struct RxTables {
     int n_sync_act;
     const cf32* ref_sym;       // fft_len : sync word 2
     const cf32* cnst_pts;      // 5 x 16 constellation points (index = constellation_type_t)
+    const double* recip_count; // frame_length * fft_len + 1 : RN(1 / k), the sample counts of the SNR estimator
 };
 
 // A stretch of the stream over which the fine-CFO oscillator runs at one held angle

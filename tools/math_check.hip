@@ -113,6 +113,32 @@ __global__ void check_div(unsigned long long* mism, unsigned long long* total, u
     atomicAdd(total, cnt);
 }
 
+// dm_div_by_count(a, n, RN(1/n)) vs a / n in double: n = 1 .. 16384, a = differences of values near 1 (the SNR
+// estimator's operands), small integers and their products, and arbitrary finite doubles
+__global__ void check_div_count(unsigned long long* mism, unsigned long long* total, unsigned long long* example)
+{
+    uint64_t st = 0xD1B54A32D192ED03ull ^ (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    auto rng = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    unsigned long long bad = 0, cnt = 0;
+    for (int it = 0; it < 16384; it++) {
+        const double n = double(1 + (rng() % 16384));
+        const double r = 1.0 / n;
+        double a;
+        switch (it & 3) {
+        case 0: a = double(__int_as_float(int(0x3f000000u + (rng() & 0xffffffu)))) - double(__int_as_float(int(0x3f000000u + (rng() & 0xffffffu)))); break;
+        case 1: a = double(rng() % 16384) * double(1 + rng() % 16384); break;
+        case 2: a = __longlong_as_double((long long)((rng() & 0x800fffffffffffffull) | ((uint64_t)(1023 - 60 + rng() % 120) << 52))); break;
+        default: a = __longlong_as_double((long long)rng()); break;
+        }
+        const double got = dm_div_by_count(a, n, r), want = a / n;
+        cnt++;
+        const bool same = __double_as_longlong(got) == __double_as_longlong(want) || (got != got && want != want);
+        if (!same) { bad++; example[0] = (unsigned long long)__double_as_longlong(a); example[1] = (unsigned long long)n; }
+    }
+    atomicAdd(mism, bad);
+    atomicAdd(total, cnt);
+}
+
 int main()
 {
     unsigned long long *d, h = 0;
@@ -138,5 +164,12 @@ int main()
     (void)hipMemcpy(h2, d2, 16, hipMemcpyDeviceToHost); (void)hipMemcpy(hex2, ex2, 8, hipMemcpyDeviceToHost);
     printf("float(double(a) * (-1/b)) and the two-correction f32 form vs -a/b: %llu mismatches over %llu operand pairs (example a=0x%08x b=0x%08x)\n",
            h2[0], h2[1], hex2[0], hex2[1]);
-    return (h != 0) || (h2[0] != 0) || (hl != 0);
+    unsigned long long *d3 = nullptr, h3[4] = { 0, 0, 0, 0 };
+    (void)hipMalloc(&d3, 32); (void)hipMemset(d3, 0, 32);
+    hipLaunchKernelGGL(check_div_count, dim3(8192), dim3(256), 0, 0, d3, d3 + 1, d3 + 2);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h3, d3, 32, hipMemcpyDeviceToHost);
+    printf("dm_div_by_count (table reciprocal, two corrections) vs a / n in double: %llu mismatches over %llu operand pairs (example a=0x%016llx n=%llu)\n",
+           h3[0], h3[1], h3[2], h3[3]);
+    return (h != 0) || (h2[0] != 0) || (hl != 0) || (h3[0] != 0);
 }
