@@ -11,6 +11,9 @@
 // FMA contraction, i.e. exactly what libgcc's __divsc3/__mulsc3 give the reference's
 // std::complex<float> code on x86-64.
 #include "rx_kernels.h"
+#ifndef DTL_ABLATE
+#define DTL_ABLATE 0 // timing experiments only (tools/ablate.sh): 1 no derotation, 2 no butterflies, 3 no equaliser
+#endif
 
 #include "dtl_math.h"
 
@@ -111,6 +114,7 @@ __device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, 
 // separate passes -- bit-identical), so the N/4 groups of four symbols keep all N lanes busy with half the
 // LDS traffic and half the barriers.  An odd last stage runs as a plain pass.  tw: the N per-pass twiddles in LDS;
 // rows are stored LDS-swizzled (fft_lds_swizzle, rx_types.h): readers index them through it.
+template <int ABL = 0> // timing experiments: see DTL_ABLATE
 __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
                                               int64_t trigger, int sym0, int n_sym, const CfoSegment* segs,
                                               int n_segs, const SegWindow& seg, cf32* buf, const cf32* tw)
@@ -149,7 +153,7 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int sidx = q + j * (N >> 2);
-                x[t.bitrev[sidx]] = cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
+                x[t.bitrev[sidx]] = ABL == 1 ? v[j] : cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
             }
         }
     } else {
@@ -164,6 +168,7 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
     }
     sync_stage();
     int st = 0;
+    if (ABL == 2) st = logN;
     for (; st + 1 < logN; st += 2) {
         if (active) {
             const int h = 1 << st;
@@ -684,7 +689,16 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
     cf32 Hk = taps_in[size_t(fd.cand) * N + k];
     const float alpha = t.eq_alpha;
     const bool occupied = t.occupied[k] != 0;
-    const cf32* pts = t.cnst_pts + fd.cnst * 16;
+    // The decided point feeds the second division of a step, which feeds the next symbol's first: a table read on
+    // that chain must be short.  This frame's constellation goes to LDS; whether carrier k is a pilot (per pilot
+    // set) becomes a bit mask in a register, and the pilot value of a step is requested before the first division.
+    __shared__ cf32 s_pts[16];
+    if (tid < 16) s_pts[tid] = t.cnst_pts[fd.cnst * 16 + tid];
+    const cf32* pts = s_pts;
+    const bool pilot_bits_ok = t.n_pilot_sets <= 32;
+    unsigned pilot_bits = 0;
+    if (pilot_bits_ok)
+        for (int ps = 0; ps < t.n_pilot_sets; ps++) pilot_bits |= (t.pilot_mask[ps * N + k] ? 1u : 0u) << ps;
     Welford w = { 0.0, 0.0, 0.0 };
     const double* __restrict__ recip = t.recip_count;
     int pilot_carr_set = t.n_pilot_sets ? h % t.n_pilot_sets : 0;
@@ -696,16 +710,23 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
     // frame_equalize for destination symbol i of this carrier (ofdm_adaptive_equalizer.cc:217-268)
     auto eq_step = [&](int i, cf32 y) {
         const int pset = (h + i) % t.n_pilot_sym_sets;
-        const bool is_pilot = t.n_pilot_sets && t.pilot_mask[pilot_carr_set * N + k];
+        const bool is_pilot = t.n_pilot_sets && (pilot_bits_ok ? ((pilot_bits >> pilot_carr_set) & 1u) != 0
+                                                              : t.pilot_mask[pilot_carr_set * N + k] != 0);
+        cf32 pilot_ref = { 0.0f, 0.0f };
+        if (is_pilot) pilot_ref = t.pilot_val[pset * N + k];
         cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
         // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
         // tap towards y / (known or decided symbol) -- so the two cases share one pair of complex divisions
         // (lanes of one wave hold both kinds; separate branches would execute both pairs)
+#if DTL_ABLATE == 3
+        if (false) {
+#else
         if (is_pilot || occupied) {
+#endif
             const cf32 eqv = cdiv(y, Hk);
             cf32 ref;
             if (is_pilot) {
-                ref = t.pilot_val[pset * N + k];
+                ref = pilot_ref;
                 // mpsk_snr_est_simple::update on |pilot_eq| (Welford, double)
                 const double x = double(sqrtf(eqv.re * eqv.re + eqv.im * eqv.im));
                 w.n += 1.0;
@@ -739,10 +760,11 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
         if (t.n_pilot_sets) pilot_carr_set = (pilot_carr_set + 1) % t.n_pilot_sets;
     };
 
+    __syncthreads();                                  // s_pts, tw
     if (lag < 0) eq_step(0, cf32{ 0.0f, 0.0f });      // its source would be row -1: the zero fill of the shift
     for (int i0 = 0; i0 < L; i0 += 4) {
         const int nb = min(4, L - i0);
-        load_and_fft4(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
+        load_and_fft4<DTL_ABLATE>(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
         for (int u = 0; u < nb; u++) {
             const int i = i0 + u - lag;               // destination symbol fed by source row i0 + u
             if (i >= 0 && i < L) {

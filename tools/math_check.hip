@@ -130,7 +130,7 @@ __global__ void check_div_count(unsigned long long* mism, unsigned long long* to
         case 2: a = __longlong_as_double((long long)((rng() & 0x800fffffffffffffull) | ((uint64_t)(1023 - 60 + rng() % 120) << 52))); break;
         default: a = __longlong_as_double((long long)rng()); break;
         }
-        const double got = dm_div_by_count(a, n, r), want = a / n;
+        const double got = dtl::dm_div_by_count(a, n, r), want = a / n;
         cnt++;
         const bool same = __double_as_longlong(got) == __double_as_longlong(want) || (got != got && want != want);
         if (!same) { bad++; example[0] = (unsigned long long)__double_as_longlong(a); example[1] = (unsigned long long)n; }
