@@ -263,10 +263,10 @@ constexpr int kSyncTile = kSyncTileSamples;   // the stream carry is aligned to 
 // strip length R (outputs per thread): 8 with 512 threads for N <= 512 (half the registers per thread, twice the
 // waves in flight), 16 with 256 threads for N = 1024 (the N/R history strips must fit one wave)
 template <int R>
-__device__ __forceinline__ int sync_pad(int j) { return j + (j / R); }
+__device__ __forceinline__ int sync_pad(int j) { return j + (j >> 4); }
 
 template <bool WITH_METRIC, int R>
-__global__ __launch_bounds__(kSyncTile / R) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
+__global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R == 8 ? 6 : 2))) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
                                                                  int64_t m_begin, int N, float thr,
                                                                  unsigned long long* __restrict__ edges,
                                                                  unsigned int* __restrict__ n_edges,
@@ -1133,7 +1133,7 @@ int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int N, float t
     if (N < 64 || (N % (2 * R)) != 0 || N / R > 64) return DTL_ERR_UNSUPPORTED; // history strips live in one wave
     const int threads = kSyncTile / R;
     const int n_raw = kSyncTile + N + N / 2;
-    const size_t lds = size_t(N / R + threads) * 3 * sizeof(double) + size_t(n_raw + n_raw / R + 2) * sizeof(cf32);
+    const size_t lds = size_t(N / R + threads) * 3 * sizeof(double) + size_t(n_raw + n_raw / 16 + 2) * sizeof(cf32);
     const int64_t grid = (n + kSyncTile - 1) / kSyncTile - m_begin / kSyncTile;
     if (grid <= 0) return DTL_OK;
     using Kern = void (*)(const cf32*, int64_t, int64_t, int, float, unsigned long long*, unsigned int*, unsigned int, float*);
