@@ -11,7 +11,7 @@ import shutil
 import sys
 
 KERNELS = {"sync_edges": "sync_edges_kernel", "trigger_angle": "trigger_angle_kernel", "header_kernel": "header_kernel",
-           "payload_kernel": "payload_kernel", "expand_cw": "expand_cw_kernel", "ldpc_bp": "ldpc_bp_np_kernel",
+           "frame_eq": "frame_eq_kernel", "demap": "demap_kernel", "expand_cw": "expand_cw_kernel", "ldpc_bp": "ldpc_bp_np_kernel",
            "tb_check": "tb_check_kernel"}
 
 
