@@ -358,7 +358,11 @@ struct Receiver::StreamState {
     long lost_total = 0;
 };
 
-Receiver::Receiver() : ss_(std::make_unique<StreamState>()) {}
+Receiver::Receiver() : ss_(std::make_unique<StreamState>())
+{
+    // tests lower the threshold so that small streams take the pipelined (four ranges, early header launches) path
+    if (const char* e = getenv("DTL_RX_SPLIT_MIN")) split_min_ = std::max<int64_t>(1, atoll(e));
+}
 
 void Receiver::reset_stream()
 {
@@ -376,6 +380,7 @@ Receiver::~Receiver()
     for (auto& e : chunk_ev_) if (e) (void)hipEventDestroy(e);
     if (ev_stats_) (void)hipEventDestroy(ev_stats_);
     for (auto& e : angle_ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& e : hdr_ev_) if (e) (void)hipEventDestroy(e);
     if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
 }
 
@@ -673,6 +678,16 @@ struct Receiver::Call {
     std::vector<AnglePart> angle_parts;
     size_t angle_parts_done = 0;  // groups whose angles are on the host and whose oscillator segments are complete
     size_t first_new_seg = 0;     // ss.segs index of this call's first trigger
+    // header kernels queued before frame_detect_bb has seen the whole trigger list (speculate_headers): record
+    // slot s holds the header found at raw trigger spec_abs[s]; launches in slot order
+    struct HdrLaunch { int s0, s1; };
+    std::vector<int64_t> spec_abs;
+    std::vector<HdrLaunch> hdr_launches;
+    size_t spec_raw_next = 0;     // first raw trigger not yet considered
+    size_t segs_uploaded = 0;     // ss.segs entries already on the device
+    size_t spec_cap = 0;          // record slots the buffers were sized for (0: not sized yet)
+    bool spec_on = true;
+    bool spec_carry_done = false; // the carried-over triggers have been offered to speculate_headers
     void lap(const char* what)
     {
         if (!dbg) return;
@@ -737,7 +752,7 @@ int Receiver::stage_sync(Call& c)
     unsigned n_edges_total = 0;
     {
         const int64_t mb0 = B - A;
-        const int n_sc = n >= (int64_t(1) << 26) ? 4 : 1;
+        const int n_sc = n >= split_min_ ? 4 : 1;
         struct Range { int64_t mb, me; unsigned max_edges, guess; size_t off; };
         std::vector<Range> rg;
         size_t edge_slots = 0;
@@ -810,6 +825,10 @@ int Receiver::stage_sync(Call& c)
                 }
                 DTL_TRY(submit_angles(c_, first, trig.size(), side_));
                 if (!last && c_.angle_parts.size() > 1) DTL_TRY(collect_angles(c_, c_.angle_parts.size() - 1));
+                // headers of the triggers whose oscillator segments are complete, up to the first trigger of this
+                // range (whose segment is not): queued behind the sync kernels, they keep the device busy while
+                // the host finishes the trigger list
+                if (!last) DTL_TRY(speculate_headers(c_, produced));
             }
         } else {
             // no new samples (a final flush): close what is open
@@ -897,6 +916,99 @@ int Receiver::collect_angles(Call& c, size_t parts)
     return DTL_OK;
 }
 
+// Phase A ahead of time.  frame_detect_bb needs the whole trigger list of a call, but it leaves nearly every raw
+// trigger where it is; so the header kernel is queued for raw triggers as soon as everything it reads is final:
+// the trigger's own oscillator segment and every segment that starts inside its header symbols (`limit` = the
+// position up to which the raw trigger list is final, cut back to the first segment still waiting for its angle).  stage_frames maps the fixed triggers onto these record
+// slots and runs the kernel only for the ones that are missing (moved or inserted triggers, the last range).
+int Receiver::speculate_headers(Call& c, int64_t limit)
+{
+    StreamState& ss = *ss_;
+    if (!c.spec_on || c.angle_parts_done == 0) return DTL_OK;
+    const int N = c.N, P = c.P;
+    const Call::AnglePart& lastp = c.angle_parts[c.angle_parts_done - 1];
+    const size_t done_raw = lastp.first + lastp.count;          // raw triggers whose segments are complete
+    const int64_t need = int64_t(c.final ? c.hdr_syms : c.hdr_syms + c.L) * P;
+    const int64_t span = int64_t(c.hdr_syms + 1) * P;
+    // first position whose oscillator state is not final: the first trigger still waiting for its angle, else the
+    // point up to which the trigger list itself is final
+    if (done_raw < raw_triggers.size()) limit = std::min(limit, raw_triggers[done_raw]);
+    std::vector<Candidate> add;
+    std::vector<int64_t> add_abs;
+    if (!c.spec_carry_done) {
+        // triggers carried over from the previous call (their frames were incomplete then) come first in the walk
+        c.spec_carry_done = true;
+        for (int64_t tpos : ss.pending_fixed) {
+            if (tpos + need > c.E || tpos + span > limit) break;
+            size_t ri = 0;
+            while (ri < ss.segs.size() && ss.segs[ri].start <= tpos) ri++;
+            if (ri > c.first_new_seg + done_raw) break;         // would read a segment that is not complete yet
+            Candidate cd{};
+            cd.trigger = tpos - c.A;
+            cd.seg = int(ri) - 1;
+            add.push_back(cd);
+            add_abs.push_back(tpos);
+        }
+    }
+    size_t j = c.spec_raw_next;
+    for (; j < done_raw; j++) {
+        const int64_t tpos = raw_triggers[j];
+        if (tpos + span > limit) break;                         // a later range decides what this header sees
+        if (tpos + need > c.E) continue;                        // never a candidate of this call
+        Candidate cd{};
+        cd.trigger = tpos - c.A;
+        cd.seg = int(c.first_new_seg + j);
+        add.push_back(cd);
+        add_abs.push_back(tpos);
+    }
+    c.spec_raw_next = j;
+    if (add.empty()) return DTL_OK;
+    if (!c.spec_cap) { // size everything the early launches write for twice the frames the call can hold
+        const size_t cap = size_t(2 * (c.W / frame_samples() + 1) + 1024);
+        const size_t seg_cap = ss.segs.size() + cap;
+        DTL_TRY(d_cands_.ensure(cap * sizeof(Candidate)));
+        DTL_TRY(h_cands_.ensure(cap * sizeof(Candidate)));
+        DTL_TRY(d_segs_.ensure(seg_cap * sizeof(CfoSegment)));
+        DTL_TRY(h_segs_.ensure(seg_cap * sizeof(CfoSegment)));
+        DTL_TRY(d_recs_.ensure(cap * sizeof(HeaderRec)));
+        DTL_TRY(h_recs_.ensure(cap * sizeof(HeaderRec)));
+        DTL_TRY(d_taps.ensure(cap * N * sizeof(cf32)));
+        if (c.flags & RX_WANT_HDR_BITS) DTL_TRY(d_hdr_bits.ensure(cap * tab_.hdr_bits));
+        c.spec_cap = cap;
+    }
+    const size_t s0 = c.spec_abs.size(), s1 = s0 + add.size();
+    const size_t segs_now = c.first_new_seg + done_raw;         // complete segments
+    if (s1 > c.spec_cap || segs_now * sizeof(CfoSegment) > d_segs_.cap || segs_now * sizeof(CfoSegment) > h_segs_.cap) {
+        c.spec_on = false;                                      // more triggers than a stream of frames produces
+        return DTL_OK;
+    }
+    std::memcpy(h_cands_.as<Candidate>() + s0, add.data(), add.size() * sizeof(Candidate));
+    DTL_HIP_CHECK(hipMemcpyAsync(d_cands_.as<Candidate>() + s0, h_cands_.as<Candidate>() + s0, add.size() * sizeof(Candidate),
+                                 hipMemcpyHostToDevice, c.st));
+    if (segs_now > c.segs_uploaded) {
+        CfoSegment* hs = h_segs_.as<CfoSegment>();
+        for (size_t k = c.segs_uploaded; k < segs_now; k++) { hs[k] = ss.segs[k]; hs[k].start -= c.A; }
+        DTL_HIP_CHECK(hipMemcpyAsync(d_segs_.as<CfoSegment>() + c.segs_uploaded, hs + c.segs_uploaded,
+                                     (segs_now - c.segs_uploaded) * sizeof(CfoSegment), hipMemcpyHostToDevice, c.st));
+        c.segs_uploaded = segs_now;
+    }
+    uint8_t* hb = (c.flags & RX_WANT_HDR_BITS) ? d_hdr_bits.as<uint8_t>() : nullptr;
+    DTL_TRY(launch_header(tab_, c.iq, c.W, d_cands_.as<Candidate>() + s0, int(add.size()), d_segs_.as<CfoSegment>(),
+                          int(c.segs_uploaded), d_recs_.as<HeaderRec>() + s0, d_taps.as<cf32>() + s0 * N,
+                          hb ? hb + s0 * tab_.hdr_bits : nullptr, c.st));
+    DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + s0, d_recs_.as<HeaderRec>() + s0, add.size() * sizeof(HeaderRec),
+                                 hipMemcpyDeviceToHost, c.st));
+    while (hdr_ev_.size() <= c.hdr_launches.size()) {
+        hipEvent_t e = nullptr;
+        DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hdr_ev_.push_back(e);
+    }
+    DTL_HIP_CHECK(hipEventRecord(hdr_ev_[c.hdr_launches.size()], c.st));
+    c.hdr_launches.push_back({ int(s0), int(s1) });
+    c.spec_abs.insert(c.spec_abs.end(), add_abs.begin(), add_abs.end());
+    return DTL_OK;
+}
+
 // K1b + frame_detect_bb + candidate list
 int Receiver::stage_triggers(Call& c)
 {
@@ -956,32 +1068,60 @@ int Receiver::stage_triggers(Call& c)
 int Receiver::stage_frames(Call& c)
 {
     RX_CALL_LOCALS(c);
-    // ---- phases A and B, pipelined over chunks of candidates: the header kernel of every chunk is queued
-    // at once; while the GPU works through them the host takes chunk after chunk of header records
-    // (header_payload_demux walk + header_parser state, both sequential) and queues that chunk's payload
-    // kernel behind them.  Only the walk of the last chunk is not hidden behind GPU work.
-    std::vector<HeaderRec> recs(n_cand);
+    // ---- phases A and B, pipelined over header-kernel launches.  Most candidates already have a record slot from a
+    // launch made during the sync stage (speculate_headers); the rest (triggers frame_detect_bb moved or inserted,
+    // the triggers of the last sample range, everything in a short call) get theirs now.  While the GPU works
+    // through the launches the host takes launch after launch of header records (header_payload_demux walk +
+    // header_parser state, both sequential) and queues the payload kernels of the frames found so far behind them.
     fdesc.clear();
     llr_off.clear();
     fdesc.reserve(n_cand);
     llr_off.reserve(n_cand);
     frames.reserve(n_cand);
-    const int n_chunks = n_cand >= 8192 ? 4 : 1;
     const int max_bps = 4;
     nofec_stride = ((capacity_ * 4 / 8 + 8) + 15) & ~15;
     cf32 *eh = nullptr, *es = nullptr, *ss_out = nullptr;
     uint8_t* nofec_bytes = nullptr;
     int32_t* nofec_inf = nullptr;
     llr_total = uint64_t(ss.llr_carry_len);
+    std::vector<int> slot(size_t(n_cand), -1);       // record slot of candidate ci
+    std::vector<HeaderRec> recs;
     if (n_cand) {
-        std::vector<CfoSegment> segs_rel(ss.segs);
-        for (auto& sg : segs_rel) sg.start -= A;
-        DTL_TRY(d_segs_.ensure(std::max<size_t>(1, segs_rel.size()) * sizeof(CfoSegment)));
-        DTL_TRY(d_recs_.ensure(size_t(n_cand) * sizeof(HeaderRec)));
-        DTL_TRY(h_recs_.ensure(size_t(n_cand) * sizeof(HeaderRec)));
-        DTL_TRY(d_taps.ensure(size_t(n_cand) * N * sizeof(cf32)));
+        // slots of the early launches, then the missing candidates in order
+        std::vector<int> extra;
+        {
+            size_t sp = 0;
+            for (int ci = 0; ci < n_cand; ci++) {
+                while (sp < c.spec_abs.size() && c.spec_abs[sp] < cand_abs[ci]) sp++;
+                if (sp < c.spec_abs.size() && c.spec_abs[sp] == cand_abs[ci]) slot[ci] = int(sp);
+                else extra.push_back(ci);
+            }
+        }
+        size_t n_slots = c.spec_abs.size() + extra.size();
+        const size_t n_segs_all = ss.segs.size();
+        if (!c.hdr_launches.empty() &&
+            (n_slots > c.spec_cap || n_segs_all * sizeof(CfoSegment) > d_segs_.cap || n_segs_all * sizeof(CfoSegment) > h_segs_.cap)) {
+            // the buffers of the early launches cannot take the rest: let them finish and start over without them
+            DTL_HIP_CHECK(hipStreamSynchronize(st));
+            c.hdr_launches.clear();
+            c.spec_abs.clear();
+            c.segs_uploaded = 0;
+            extra.resize(size_t(n_cand));
+            for (int ci = 0; ci < n_cand; ci++) { slot[ci] = -1; extra[ci] = ci; }
+            n_slots = extra.size();
+        }
+        const size_t s_base = c.spec_abs.size();
+        for (size_t e = 0; e < extra.size(); e++) slot[extra[e]] = int(s_base + e);
+        recs.resize(n_slots);
+        DTL_TRY(d_cands_.ensure(n_slots * sizeof(Candidate)));
+        DTL_TRY(h_cands_.ensure(n_slots * sizeof(Candidate)));
+        DTL_TRY(d_segs_.ensure(std::max<size_t>(1, n_segs_all) * sizeof(CfoSegment)));
+        DTL_TRY(h_segs_.ensure(std::max<size_t>(1, n_segs_all) * sizeof(CfoSegment)));
+        DTL_TRY(d_recs_.ensure(n_slots * sizeof(HeaderRec)));
+        DTL_TRY(h_recs_.ensure(n_slots * sizeof(HeaderRec)));
+        DTL_TRY(d_taps.ensure(n_slots * N * sizeof(cf32)));
         uint8_t* hb = nullptr;
-        if (flags & RX_WANT_HDR_BITS) { DTL_TRY(d_hdr_bits.ensure(size_t(n_cand) * tab_.hdr_bits)); hb = d_hdr_bits.as<uint8_t>(); }
+        if (flags & RX_WANT_HDR_BITS) { DTL_TRY(d_hdr_bits.ensure(n_slots * tab_.hdr_bits)); hb = d_hdr_bits.as<uint8_t>(); }
         // per-frame buffers of phase B, sized for "every candidate becomes a frame at the densest constellation"
         const uint64_t llr_bound = llr_total + uint64_t(n_cand) * capacity_ * max_bps;
         DTL_TRY(d_llr.ensure((size_t(std::min<uint64_t>(llr_bound, 0xFFFFFFF0ull)) + 4096) * 4));
@@ -1006,83 +1146,104 @@ int Receiver::stage_frames(Call& c)
             nofec_bytes = d_staging_.as<uint8_t>();
             nofec_inf = d_nofec_info_.as<int32_t>();
         }
-        DTL_TRY(upload_vec(h_cands_, d_cands_, cands, st));
-        DTL_TRY(upload_vec(h_segs_, d_segs_, segs_rel, st));
-        while (int(chunk_ev_.size()) < n_chunks) {
-            hipEvent_t e = nullptr;
-            DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            chunk_ev_.push_back(e);
+        // the remaining oscillator segments, then the missing candidates in up to four launches
+        if (n_segs_all > c.segs_uploaded) {
+            CfoSegment* hs = h_segs_.as<CfoSegment>();
+            for (size_t k = c.segs_uploaded; k < n_segs_all; k++) { hs[k] = ss.segs[k]; hs[k].start -= A; }
+            DTL_HIP_CHECK(hipMemcpyAsync(d_segs_.as<CfoSegment>() + c.segs_uploaded, hs + c.segs_uploaded,
+                                         (n_segs_all - c.segs_uploaded) * sizeof(CfoSegment), hipMemcpyHostToDevice, st));
+            c.segs_uploaded = n_segs_all;
         }
-        for (int c = 0; c < n_chunks; c++) {
-            const int c0 = int(int64_t(n_cand) * c / n_chunks), c1 = int(int64_t(n_cand) * (c + 1) / n_chunks);
-            if (c1 <= c0) continue;
-            DTL_TRY(launch_header(tab_, iq, W, d_cands_.as<Candidate>() + c0, c1 - c0, d_segs_.as<CfoSegment>(), n_segs,
-                                  d_recs_.as<HeaderRec>() + c0, d_taps.as<cf32>() + size_t(c0) * N,
-                                  hb ? hb + size_t(c0) * tab_.hdr_bits : nullptr, st));
-            DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + c0, d_recs_.as<HeaderRec>() + c0,
-                                         size_t(c1 - c0) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
-            DTL_HIP_CHECK(hipEventRecord(chunk_ev_[c], st));
+        if (!extra.empty()) {
+            Candidate* hc = h_cands_.as<Candidate>() + s_base;
+            for (size_t e = 0; e < extra.size(); e++) hc[e] = cands[extra[e]];
+            DTL_HIP_CHECK(hipMemcpyAsync(d_cands_.as<Candidate>() + s_base, hc, extra.size() * sizeof(Candidate), hipMemcpyHostToDevice, st));
+            const int n_extra = int(extra.size()), n_parts = n_extra >= 8192 ? 4 : 1;
+            for (int part = 0; part < n_parts; part++) {
+                const int e0 = int(int64_t(n_extra) * part / n_parts), e1 = int(int64_t(n_extra) * (part + 1) / n_parts);
+                if (e1 <= e0) continue;
+                const size_t s0 = s_base + size_t(e0);
+                DTL_TRY(launch_header(tab_, iq, W, d_cands_.as<Candidate>() + s0, e1 - e0, d_segs_.as<CfoSegment>(), n_segs,
+                                      d_recs_.as<HeaderRec>() + s0, d_taps.as<cf32>() + s0 * N,
+                                      hb ? hb + s0 * tab_.hdr_bits : nullptr, st));
+                DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + s0, d_recs_.as<HeaderRec>() + s0,
+                                             size_t(e1 - e0) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
+                while (hdr_ev_.size() <= c.hdr_launches.size()) {
+                    hipEvent_t e = nullptr;
+                    DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    hdr_ev_.push_back(e);
+                }
+                DTL_HIP_CHECK(hipEventRecord(hdr_ev_[c.hdr_launches.size()], st));
+                c.hdr_launches.push_back({ int(s0), int(s0) + (e1 - e0) });
+            }
         }
     }
     int n_walked = 0; // candidates the demux has dealt with
     bool stop = false, payload_started = false;
-    for (int c = 0; c < n_chunks && n_cand; c++) {
-        const int c0 = int(int64_t(n_cand) * c / n_chunks), c1 = int(int64_t(n_cand) * (c + 1) / n_chunks);
-        if (c1 <= c0) continue;
-        DTL_HIP_CHECK(hipEventSynchronize(chunk_ev_[c]));
-        if (c == 0) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }
-        std::memcpy(recs.data() + c0, h_recs_.as<HeaderRec>() + c0, size_t(c1 - c0) * sizeof(HeaderRec));
-        const int f0 = int(fdesc.size());
-        for (int ci = c0; ci < c1 && !stop; ci++) {
-            const int64_t trig = cand_abs[ci];
-            n_walked = ci + 1;
-            if (trig < ss.demux_pos) continue; // consumed by a previous frame
-            const HeaderRec& r = recs[ci];
-            FrameInfo fi{};
-            fi.trigger = trig; fi.header_ok = r.crc_ok; fi.carr_offset = r.carr_offset; fi.payload_index = -1; fi.cand = ci;
-            fi.llr_offset = -1;
-            if (!r.crc_ok) { frames.push_back(fi); ss.demux_pos = trig + 1; continue; }
-            if (trig + int64_t(hdr_syms + L) * P > E) { stop = true; break; } // only at the end of a stream
-            if (r.cnst && r.cnst <= 4) ss.state_cnst = r.cnst; // :269-273
-            const int bps = bits_per_symbol(ss.state_cnst);
-            int n_syms = r.payload_len * 8 / bps;
-            if (r.payload_len * 8 % bps) n_syms++;
-            fi.payload_len = r.payload_len; fi.frame_no = r.frame_no; fi.cnst = ss.state_cnst; fi.fb_cnst = r.fb_cnst;
-            fi.tb_no = r.tb_no; fi.fec_fb = r.fec_fb; fi.tb_offset = r.tb_offset; fi.fec = r.fec; fi.tb_payload = r.tb_payload;
-            fi.n_payload_syms = n_syms;
-            fi.payload_index = int(fdesc.size());
-            FrameDesc d{};
-            d.trigger = trig - A; d.seg = cands[ci].seg; d.cand = ci; d.cnst = ss.state_cnst; d.carr_offset = r.carr_offset;
-            // ofdm_serializer_vcc truncation to packet_length; payload == 0 frames are dropped (:218,254)
-            d.n_syms = r.payload_len ? std::min(n_syms, capacity_) : 0;
-            // soft-bit stream layout: frame after frame, behind the soft bits carried for an unfinished TB
-            fi.llr_offset = int64_t(llr_total);
-            llr_off.push_back(uint32_t(llr_total));
-            llr_total += uint64_t(d.n_syms) * bps;
-            if (llr_total + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
-            fdesc.push_back(d);
-            frames.push_back(fi);
-            ss.demux_pos = trig + int64_t(hdr_syms + L) * P;
-        }
-        // ---- phase B for the frames of this chunk (tb bookkeeping runs on the host while it executes)
+    size_t ready = 0; // header launches whose records are on the host
+    int f0 = 0;       // frames already handed to phase B
+    // phase B for the frames found so far (tb bookkeeping runs on the host while it executes)
+    auto flush_payload = [&]() -> int {
         const int f1 = int(fdesc.size());
-        if (f1 > f0) {
-            std::memcpy(h_frames_.as<FrameDesc>() + f0, fdesc.data() + f0, size_t(f1 - f0) * sizeof(FrameDesc));
-            std::memcpy(h_llr_off_.as<uint32_t>() + f0, llr_off.data() + f0, size_t(f1 - f0) * 4);
-            DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.as<FrameDesc>() + f0, h_frames_.as<FrameDesc>() + f0,
-                                         size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
-            DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.as<uint32_t>() + f0, h_llr_off_.as<uint32_t>() + f0, size_t(f1 - f0) * 4,
-                                         hipMemcpyHostToDevice, st));
-            if (!payload_started && ev_[0]) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
-            DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
-                                   d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0, d_llr_off_.as<uint32_t>() + f0,
-                                   d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
-                                   ss_out + size_t(f0) * capacity_,
-                                   nofec_bytes ? nofec_bytes + size_t(f0) * nofec_stride : nullptr,
-                                   nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st));
+        if (f1 <= f0) return DTL_OK;
+        std::memcpy(h_frames_.as<FrameDesc>() + f0, fdesc.data() + f0, size_t(f1 - f0) * sizeof(FrameDesc));
+        std::memcpy(h_llr_off_.as<uint32_t>() + f0, llr_off.data() + f0, size_t(f1 - f0) * 4);
+        DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.as<FrameDesc>() + f0, h_frames_.as<FrameDesc>() + f0,
+                                     size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.as<uint32_t>() + f0, h_llr_off_.as<uint32_t>() + f0, size_t(f1 - f0) * 4,
+                                     hipMemcpyHostToDevice, st));
+        if (!payload_started && ev_[0]) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
+        DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
+                               d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0, d_llr_off_.as<uint32_t>() + f0,
+                               d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
+                               ss_out + size_t(f0) * capacity_,
+                               nofec_bytes ? nofec_bytes + size_t(f0) * nofec_stride : nullptr,
+                               nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st));
+        f0 = f1;
+        return DTL_OK;
+    };
+    for (int ci = 0; ci < n_cand && !stop; ci++) {
+        const int sl = slot[ci];
+        // records of this candidate's launch (and of every launch before it) on the host?
+        while (ready < c.hdr_launches.size() && sl >= c.hdr_launches[ready].s0) {
+            DTL_TRY(flush_payload());
+            DTL_HIP_CHECK(hipEventSynchronize(hdr_ev_[ready]));
+            if (ready == 0) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }
+            const Call::HdrLaunch& hl = c.hdr_launches[ready];
+            std::memcpy(recs.data() + hl.s0, h_recs_.as<HeaderRec>() + hl.s0, size_t(hl.s1 - hl.s0) * sizeof(HeaderRec));
+            ready++;
         }
-        if (stop) break;
+        const int64_t trig = cand_abs[ci];
+        n_walked = ci + 1;
+        if (trig < ss.demux_pos) continue; // consumed by a previous frame
+        const HeaderRec& r = recs[sl];
+        FrameInfo fi{};
+        fi.trigger = trig; fi.header_ok = r.crc_ok; fi.carr_offset = r.carr_offset; fi.payload_index = -1; fi.cand = sl;
+        fi.llr_offset = -1;
+        if (!r.crc_ok) { frames.push_back(fi); ss.demux_pos = trig + 1; continue; }
+        if (trig + int64_t(hdr_syms + L) * P > E) { stop = true; break; } // only at the end of a stream
+        if (r.cnst && r.cnst <= 4) ss.state_cnst = r.cnst; // :269-273
+        const int bps = bits_per_symbol(ss.state_cnst);
+        int n_syms = r.payload_len * 8 / bps;
+        if (r.payload_len * 8 % bps) n_syms++;
+        fi.payload_len = r.payload_len; fi.frame_no = r.frame_no; fi.cnst = ss.state_cnst; fi.fb_cnst = r.fb_cnst;
+        fi.tb_no = r.tb_no; fi.fec_fb = r.fec_fb; fi.tb_offset = r.tb_offset; fi.fec = r.fec; fi.tb_payload = r.tb_payload;
+        fi.n_payload_syms = n_syms;
+        fi.payload_index = int(fdesc.size());
+        FrameDesc d{};
+        d.trigger = trig - A; d.seg = cands[ci].seg; d.cand = sl; d.cnst = ss.state_cnst; d.carr_offset = r.carr_offset;
+        // ofdm_serializer_vcc truncation to packet_length; payload == 0 frames are dropped (:218,254)
+        d.n_syms = r.payload_len ? std::min(n_syms, capacity_) : 0;
+        // soft-bit stream layout: frame after frame, behind the soft bits carried for an unfinished TB
+        fi.llr_offset = int64_t(llr_total);
+        llr_off.push_back(uint32_t(llr_total));
+        llr_total += uint64_t(d.n_syms) * bps;
+        if (llr_total + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
+        fdesc.push_back(d);
+        frames.push_back(fi);
+        ss.demux_pos = trig + int64_t(hdr_syms + L) * P;
     }
+    DTL_TRY(flush_payload());
     if (!n_cand) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }
     if (payload_started && ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
     if (fdesc.size()) { // per-frame SNR estimates travel back while the decoder runs
