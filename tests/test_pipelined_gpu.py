@@ -1,0 +1,93 @@
+"""The pipelined form of a call (sync stage in four sample ranges, arg(P) on a side stream, header kernels queued
+for raw triggers before frame_detect_bb has seen the whole list) normally starts at 2^26 samples per call.  Here
+the threshold is lowered (DTL_RX_SPLIT_MIN, read when a receiver is created) so that small streams take that path,
+and the results are compared with the oracle and, record by record, with the unsplit path -- including streams
+where frame_detect_bb moves / inserts triggers (jitter, lost preambles), a carrier-frequency offset, and
+chunked feed() calls that carry triggers over."""
+import numpy as np
+import pytest
+
+from helpers import make_pair, make_stream, oracle_feedback
+from test_stream_gpu import FRAME_KEYS, TB_KEYS, _assert_same, _feed_all
+
+
+@pytest.fixture()
+def split_env(monkeypatch):
+    monkeypatch.setenv("DTL_RX_SPLIT_MIN", "20000")
+
+
+def _jittered(oracle, ocfg, code, cnst, n_bytes, esn0, seed, drop_every=0, jitter=0):
+    """Frames with a few samples inserted between them (trigger jitter for frame_detect_bb) and some preambles blanked."""
+    user, hdrs, x = make_stream(oracle, ocfg, code, cnst, n_bytes, esn0, seed)
+    if not (drop_every or jitter):
+        return user, x
+    fs = (2 + 2 + ocfg.frame_length) * (ocfg.fft_len + ocfg.cp_len)
+    rng = np.random.default_rng(seed + 7)
+    parts = [x[:100]]
+    for f in range((len(x) - 100) // fs):
+        fr = x[100 + f * fs:100 + (f + 1) * fs].copy()
+        if drop_every and f % drop_every == drop_every - 1:
+            fr[:ocfg.fft_len + ocfg.cp_len] *= 0.05          # first sync word nearly gone: the detector misses it
+        parts.append(fr)
+        if jitter and f % 5 == 2:
+            n_ins = int(rng.integers(1, jitter + 1))
+            parts.append((rng.normal(0, 1e-3, n_ins) + 1j * rng.normal(0, 1e-3, n_ins)).astype(np.complex64))
+    parts.append(x[100 + ((len(x) - 100) // fs) * fs:])
+    return user, np.concatenate(parts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fft_len,cnst,esn0,n_bytes,drop,jitter,cfo", [
+    (64, 2, 13.0, 20000, 0, 0, 0.0),
+    (64, 4, 24.0, 24000, 7, 2, 0.0),
+    (64, 3, 21.0, 16000, 0, 3, 0.3),
+    (256, 4, 24.0, 40000, 5, 1, 0.0),
+])
+def test_pipelined_call_matches_oracle_and_unsplit(oracle, dtl, cuda, split_env, monkeypatch, fft_len, cnst, esn0, n_bytes,
+                                                  drop, jitter, cfo):
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, sync_threshold=0.95 if fft_len == 64 else 0.98)
+    user, x = _jittered(oracle, ocfg, code, cnst, n_bytes, esn0, seed=31 + cnst, drop_every=drop, jitter=jitter)
+    if cfo:
+        x = (x * np.exp(2j * np.pi * cfo / fft_len * np.arange(len(x)))).astype(np.complex64)
+    assert len(x) > 4 * 20000
+    xt = torch.from_numpy(x).to(cuda)
+    rx = dtl.ofdm_receiver(pcfg)                               # pipelined
+    res = rx.work(xt)
+    monkeypatch.setenv("DTL_RX_SPLIT_MIN", str(1 << 40))
+    rx_plain = dtl.ofdm_receiver(pcfg)                         # one range, no early launches
+    ref_gpu = rx_plain.work(xt)
+    np.testing.assert_array_equal(res.raw_triggers, ref_gpu.raw_triggers)
+    np.testing.assert_array_equal(res.fixed_triggers, ref_gpu.fixed_triggers)
+    np.testing.assert_array_equal(res.sc_freq.view(np.uint32), ref_gpu.sc_freq.view(np.uint32))
+    assert len(res.frames) == len(ref_gpu.frames) > 20
+    for k in FRAME_KEYS:
+        a, b = res.frames[k], ref_gpu.frames[k]
+        np.testing.assert_array_equal(a.view(np.uint64) if a.dtype.kind == "f" else a,
+                                      b.view(np.uint64) if b.dtype.kind == "f" else b, err_msg=k)
+    for k in TB_KEYS:
+        np.testing.assert_array_equal(res.tbs[k], ref_gpu.tbs[k], err_msg=k)
+    assert torch.equal(res.payload, ref_gpu.payload)
+    # and the oracle
+    ref = oracle.rx_stream(ocfg, code, x, feedback=oracle_feedback(oracle, pcfg, rx), want=("frames", "trig"))
+    np.testing.assert_array_equal(res.raw_triggers, np.nonzero(ref["trig_raw"])[0])
+    np.testing.assert_array_equal(res.fixed_triggers, np.nonzero(ref["trig_fixed"])[0])
+    assert [(t["tb_no"], t["crc_ok"], t["avg_it"]) for t in res.tbs] == [(t["tb_no"], t["crc_ok"], t["avg_it"]) for t in ref["tbs"]]
+    np.testing.assert_array_equal(res.payload.cpu().numpy(), ref["user_bytes"])
+    if drop or jitter:
+        assert not np.array_equal(res.raw_triggers, res.fixed_triggers)   # frame_detect_bb did change the list
+
+
+@pytest.mark.gpu
+def test_pipelined_feed_with_carried_triggers(oracle, dtl, cuda, split_env):
+    """Chunked feed(): every call is large enough to be pipelined and starts with triggers carried over."""
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=64, sync_threshold=0.95)
+    user, x = _jittered(oracle, ocfg, code, 2, 30000, 14.0, seed=77, drop_every=9, jitter=2)
+    xt = torch.from_numpy(x).to(cuda)
+    batch = dtl.ofdm_receiver(pcfg).work(xt)
+    rx = dtl.ofdm_receiver(pcfg)
+    n = xt.numel()
+    cuts = [n // 3 + 411, 2 * n // 3 + 1007]
+    assert min(np.diff([0] + cuts + [n])) > 20000
+    _assert_same(batch, _feed_all(rx, xt, cuts))
