@@ -544,35 +544,72 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     }
     if (hdr_bits_out)
         for (int b = tid; b < t.hdr_bits; b += blockDim.x) hdr_bits_out[size_t(blockIdx.x) * t.hdr_bits + b] = bits[b];
-    if (tid == 0) {
-        // header_parser (packet_header.cc:231-312), bits_per_byte == 1
-        HeaderRec r{};
-        const int HL = t.hdr_bits;
-        int k = 0;
-        auto field = [&](int nb) { int v = 0; for (int i = 0; i < nb && k < HL; i++, k++) v |= (bits[k] & 1) << i; return v; };
-        r.payload_len = field(12);
-        r.frame_no = field(12);
-        r.cnst = field(4);
-        r.fb_cnst = field(4);
-        if (t.has_fec) {
-            r.tb_no = field(12); r.fec_fb = field(4); r.tb_offset = field(12); r.fec = field(4); r.tb_payload = field(16);
+    // header_parser (packet_header.cc:231-312), bits_per_byte == 1.  The work is spread over the lanes of wave 0
+    // (one lane used to walk ~900 LDS bytes and 400 CRC bit steps while the workgroup's LDS stayed allocated):
+    // the header bits become ballot words, the CRC input bytes are packed one per lane, the CRC-16 register runs
+    // byte-wise through a 256-entry table built by all threads.
+    const int HL = t.hdr_bits;
+    uint16_t* crc_tab = reinterpret_cast<uint16_t*>(Y);                 // the FFT rows are dead: 256 table entries,
+    uint8_t* crc_buf = reinterpret_cast<uint8_t*>(Y) + 512;             // then the CRC input bytes
+    int len = (HL - 16) / 8;
+    if ((HL - 16) % 8) ++len;
+    const bool table_fits = 512 + size_t(len > 0 ? len : 0) <= size_t(2 + h) * N * sizeof(cf32);
+    if (table_fits) {
+        for (int e = tid; e < 256; e += blockDim.x) { // MSB-first CRC-16, polynomial 0x1021: register after byte e
+            uint32_t reg = uint32_t(e) << 8;
+            for (int b = 0; b < 8; b++) reg = (reg & 0x8000u) ? ((reg << 1) ^ 0x1021u) : (reg << 1);
+            crc_tab[e] = uint16_t(reg);
         }
         // pack_crc (:93-105) keeps the reference's loop bound i*len+j < header_len
-        uint8_t* crc_buf = reinterpret_cast<uint8_t*>(gabs); // gabs is dead; (HL-16)/8+1 <= N/2*4 bytes
-        int len = (HL - 16) / 8;
-        if ((HL - 16) % 8) ++len;
-        for (int i = 0; i < len; i++) {
+        for (int i = tid; i < len; i += blockDim.x) {
             uint8_t v = 0;
             for (int j = 0; j < 8 && i * len + j < HL; j++) v = uint8_t((v << 1) | (bits[i * 8 + j] & 1));
             crc_buf[i] = v;
         }
-        const uint32_t crc = crc_bits(crc_buf, len, 16, 0x1021u, 0xFFFFu, 0u, false, true);
-        int ok = 1;
-        for (int i = 0; i < 16 && k < HL; i++, k++)
-            if (uint32_t(bits[k] & 1) != ((crc >> i) & 1u)) ok = 0;
-        r.crc_ok = ok;
-        r.carr_offset = off;
-        recs[blockIdx.x] = r;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // header bit k (k < 128 covers every field and the CRC of both header layouts) as bit k of two ballots
+        const int f_bits = t.has_fec ? 80 : 32;
+        const unsigned long long w0 = __ballot(tid < HL && (bits[tid < HL ? tid : 0] & 1));
+        const unsigned long long w1 = __ballot(tid + 64 < HL && (bits[tid + 64 < HL ? tid + 64 : 0] & 1));
+        // the 16 CRC bits follow the fields (positions f_bits .. f_bits+15, cut at HL)
+        if (tid == 0) {
+            HeaderRec r{};
+            int k = 0;
+            auto field = [&](int nb) {
+                int v = 0;
+                for (int i = 0; i < nb && k < HL; i++, k++) v |= int(((k < 64 ? w0 >> k : w1 >> (k - 64)) & 1ull)) << i;
+                return v;
+            };
+            r.payload_len = field(12);
+            r.frame_no = field(12);
+            r.cnst = field(4);
+            r.fb_cnst = field(4);
+            if (t.has_fec) {
+                r.tb_no = field(12); r.fec_fb = field(4); r.tb_offset = field(12); r.fec = field(4); r.tb_payload = field(16);
+            }
+            (void)f_bits;
+            uint32_t crc;
+            if (table_fits) {
+                uint32_t reg = 0xFFFFu;
+                for (int i = 0; i < len; i++) reg = ((reg << 8) & 0xFFFFu) ^ crc_tab[((reg >> 8) ^ crc_buf[i]) & 0xFFu];
+                crc = __brev(reg) >> 16;                               // refout, no final xor
+            } else {
+                for (int i = 0; i < len; i++) {
+                    uint8_t v = 0;
+                    for (int j = 0; j < 8 && i * len + j < HL; j++) v = uint8_t((v << 1) | (bits[i * 8 + j] & 1));
+                    crc_buf[i] = v;
+                }
+                crc = crc_bits(crc_buf, len, 16, 0x1021u, 0xFFFFu, 0u, false, true);
+            }
+            int ok = 1;
+            for (int i = 0; i < 16 && k < HL; i++, k++)
+                if (uint32_t((k < 64 ? w0 >> k : w1 >> (k - 64)) & 1ull) != ((crc >> i) & 1u)) ok = 0;
+            r.crc_ok = ok;
+            r.carr_offset = off;
+            recs[blockIdx.x] = r;
+        }
     }
 }
 
