@@ -471,20 +471,26 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     if (search_in_lds) {
         const int per = n_act <= N / 2 ? N / 2 : N;          // lanes reserved per offset
         const int groups = N / per, grp = tid / per, a = tid - grp * per;
-        if (a < n_act) {
-            const int k = t.sync_act[a];
-            const cf32 cvc = cconj(t.corr_v[k]);
-            for (int gi = grp; gi < n_g; gi += groups) {
-                const int g = t.g_min + 2 * gi;
-                terms[gi * (n_act + 1) + a] = cmul(cmul(cconj(ysh(0, k + g)), cvc), ysh(1, k + g));
+        // two rounds over half of the offsets each: half the LDS for the products, more workgroups per CU
+        const int rows = (n_g + 1) / 2;
+        for (int g0 = 0; g0 < n_g; g0 += rows) {
+            const int g1 = min(g0 + rows, n_g);
+            if (a < n_act) {
+                const int k = t.sync_act[a];
+                const cf32 cvc = cconj(t.corr_v[k]);
+                for (int gi = g0 + grp; gi < g1; gi += groups) {
+                    const int g = t.g_min + 2 * gi;
+                    terms[(gi - g0) * (n_act + 1) + a] = cmul(cmul(cconj(ysh(0, k + g)), cvc), ysh(1, k + g));
+                }
             }
-        }
-        __syncthreads();
-        if (tid < n_g) {
-            cf32 acc = { 0.0f, 0.0f };
-            const cf32* row = terms + tid * (n_act + 1);
-            for (int i = 0; i < n_act; i++) acc = cadd(acc, row[i]);
-            gabs[tid] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+            __syncthreads();
+            if (tid < g1 - g0) {
+                cf32 acc = { 0.0f, 0.0f };
+                const cf32* row = terms + tid * (n_act + 1);
+                for (int i = 0; i < n_act; i++) acc = cadd(acc, row[i]);
+                gabs[g0 + tid] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+            }
+            __syncthreads();                                 // the rows are rewritten by the next round
         }
     } else {
         for (int gi = tid; gi < n_g; gi += blockDim.x) {
@@ -1201,7 +1207,7 @@ int launch_trigger_angle(const cf32* iq, int64_t n, int N, const int64_t* trig, 
 static size_t header_search_bytes(const RxTables& t)
 {
     const int n_g = (t.g_max - t.g_min) / 2 + 1;
-    return size_t(n_g) * (t.n_sync_act + 1) * sizeof(cf32);
+    return size_t((n_g + 1) / 2) * (t.n_sync_act + 1) * sizeof(cf32); // two rounds over half of the offsets
 }
 
 // the products of the offset search live in LDS when they are few enough to leave room for several workgroups
