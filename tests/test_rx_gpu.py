@@ -147,10 +147,12 @@ def test_no_fec_chain_matches_oracle(oracle, dtl, cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fft_len,frame_length,thr,esn0", [(256, 20, 0.985, 24.0), (1024, 10, 0.99, 27.0)])
+# 128 and 512 have an odd number of butterfly stages (the plain last pass of the two-stages-per-pass FFT)
+@pytest.mark.parametrize("fft_len,frame_length,thr,esn0", [(128, 20, 0.97, 24.0), (256, 20, 0.985, 24.0),
+                                                          (512, 12, 0.985, 25.0), (1024, 10, 0.99, 27.0)])
 def test_fec_chain_matches_oracle_large_fft(oracle, dtl, cuda, fft_len, frame_length, thr, esn0):
     pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, sync_threshold=thr)
-    user, hdrs, x = make_stream(oracle, ocfg, code, 4, 40000 if fft_len == 256 else 60000, esn0, seed=fft_len)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 4, {128: 20000, 256: 40000, 512: 50000, 1024: 60000}[fft_len], esn0, seed=fft_len)
     rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
     assert ref["n_frames"] > 0.5 * len(hdrs)
     _compare(rx, res, ref, ocfg, True)
