@@ -141,3 +141,57 @@ def test_shard_plan_and_block_ownership():
     tbs2 = np.zeros(2, dtype=tdt)
     tbs2["tb_no"] = [2, 5]
     assert list(tbs2["tb_no"][owned_blocks(frames2, tbs2, p)]) == [5]
+
+
+def test_block_ownership_against_ground_truth_with_losses():
+    """Random streams of frames and blocks with lost frames, incomplete blocks, blocks spanning several frames and
+    wrapping 8-bit block numbers: the records-only matching of owned_blocks must reproduce the ownership known
+    from the construction."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from gr_dtl_amd.sharding import owned_blocks
+    fdt = np.dtype([("trigger", "<i8"), ("payload_index", "<i4"), ("payload_len", "<i4"), ("tb_no", "<i4")])
+    tdt = np.dtype([("tb_no", "<i4"), ("crc_ok", "<i4")])
+    rng = np.random.default_rng(11)
+    fs = 1000
+    for trial in range(40):
+        n_frames = int(rng.integers(50, 900))
+        span = float(rng.choice([1.02, 1.4, 0.6, 2.3]))           # block length in frame payloads
+        lost = rng.random(n_frames) < rng.choice([0.0, 0.03, 0.15])
+        start_sample = int(rng.integers(0, 5000))
+        own_lo = start_sample + int(rng.integers(0, n_frames // 2)) * fs
+        own_hi = own_lo + int(rng.integers(1, n_frames)) * fs
+        plan = dict(start=start_sample, own_lo=own_lo, own_hi=own_hi)
+        # block b covers stream positions [b*span, (b+1)*span) in units of frames; it starts in frame floor(b*span)
+        n_blocks = int(n_frames / span)
+        frames, tb_rows, truth = [], [], []
+        first_block_of_frame = {}
+        for b in range(n_blocks):
+            first_block_of_frame.setdefault(int(np.floor(b * span)), b)
+        last_named = 1
+        for f in range(n_frames):
+            # the header names the (first) block that starts in this frame; a frame inside a long block repeats it
+            named = first_block_of_frame.get(f)
+            if named is None:
+                named = last_named
+            last_named = named
+            if lost[f]:
+                continue
+            frames.append((f * fs + 70, len(frames), 100, (named + 1) % 256))
+        for b in range(n_blocks):
+            f0, f1 = int(np.floor(b * span)), int(np.floor((b + 1) * span - 1e-9))
+            if f1 >= n_frames or lost[f0]:
+                continue                                           # never started (or runs past the stream)
+            # completes if its start frame is there; a lost later frame makes it fail its CRC but it is still recorded
+            ok = not lost[f0:f1 + 1].any()
+            if first_block_of_frame.get(f0) != b:
+                continue                                           # second block starting in one frame: not modelled
+            tb_rows.append(((b + 1) % 256, int(ok)))
+            truth.append(own_lo <= start_sample + f0 * fs + 70 < own_hi)
+        if not tb_rows or not frames:
+            continue
+        fr = np.array(frames, dtype=fdt)
+        tb = np.array(tb_rows, dtype=tdt)
+        keep = owned_blocks(fr, tb, plan)
+        want = np.nonzero(np.array(truth))[0]
+        assert np.array_equal(keep, want), (trial, span, keep[:10], want[:10])
