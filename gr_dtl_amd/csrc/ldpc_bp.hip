@@ -17,6 +17,8 @@
 //    the stride averages the imbalance); 16 single-wave workgroups fit a CU's 160 KB LDS.
 #include "ldpc_bp.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -263,6 +265,62 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         }
         return chunk_next++;
     };
+    auto check_phase = [&](auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        // ---- update_chks: lane == check node.  When the last pass would fill at most half of the wave
+        // (148 checks = 64 + 64 + 20), it runs with TWO lanes per check instead, each owning half of the
+        // row: half the divisions per lane, and the row product is still formed in the reference's
+        // order (the even lane multiplies its factors, hands the partial product to the odd lane, which
+        // multiplies its own on top and hands the result back).
+        int c0 = 0;
+        for (; c0 + kWave <= t.m || t.m - c0 > kWave / 2; c0 += kWave) {
+            const int c = c0 + lane;
+            if (c < t.m) {
+                double* row = msg + c * MAXR;
+                double tt[MAXR];
+#pragma unroll
+                for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + (FIRST ? rx[chk_var[c * MAXR + j]] : row[j])) - 1;
+                double product = 1.0;
+#pragma unroll
+                for (int j = 0; j < MAXR; j++) product = product * tt[j];
+                const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
+#pragma unroll
+                for (int j = 0; j < MAXR; j++) {
+                    const double prd = product / tt[j];
+                    const double val = (1 - prd) / (1 + prd);
+                    row[j] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
+                }
+            }
+        }
+        if (c0 < t.m) {
+            constexpr int HR = MAXR / 2;
+            const int c = c0 + (lane >> 1);
+            const bool upper = lane & 1;
+            const bool valid = c < t.m;
+            double* row = msg + (valid ? c : 0) * MAXR + (upper ? HR : 0);
+            double tt[HR];
+#pragma unroll
+            for (int j = 0; j < HR; j++)
+                tt[j] = 2 / (1 + (FIRST ? rx[chk_var[(valid ? c : 0) * MAXR + (upper ? HR : 0) + j]] : row[j])) - 1;
+            double part = 1.0;
+#pragma unroll
+            for (int j = 0; j < HR; j++) part = part * tt[j];             // even lane: ((1 t0) t1) t2
+            double product = __shfl_xor(part, 1);                         // odd lane: the even lane's partial
+#pragma unroll
+            for (int j = 0; j < HR; j++) product = product * tt[j];       // odd lane: ... t3) t4) t5
+            const double back = __shfl_xor(product, 1);                   // even lane: the finished product
+            if (!upper) product = back;
+            const int deg = ROWS_FULL ? MAXR : int(chk_deg[valid ? c : 0]);
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < HR; j++) {
+                    const double prd = product / tt[j];
+                    const double val = (1 - prd) / (1 + prd);
+                    row[j] = (ROWS_FULL || (upper ? HR : 0) + j < deg) ? val : 0.0;
+                }
+            }
+        }
+    };
     float cur[NV], nxt[NV];
     Meta mcur{ 0, 0 }, mnxt{ 0, 0 };
     int cw = advance();
@@ -290,63 +348,14 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             for (int v = lane; v < t.n; v += kWave) rx[v] = exp(double((-1 * 2 * ybuf[v]) / s2));
             if (lane == 0) rx[t.n] = 0.0;
             wave_sync();
-            for (int e = lane; e < n_slots; e += kWave) msg[e] = rx[chk_var[e]];
+            // spa_initialize (Q_e = channel LR of the edge's variable) is folded into the first check pass, which reads
+            // rx through the row's variable indices instead of the message slots
             if (lane == 0) { msg[kOneSlot] = 1.0; msg[kTrashSlot] = 0.0; }
             wave_sync();
             while (nit < max_it) {
                 nit += 1;
-                // ---- update_chks: lane == check node.  When the last pass would fill at most half of the wave
-                // (148 checks = 64 + 64 + 20), it runs with TWO lanes per check instead, each owning half of the
-                // row: half the divisions per lane, and the row product is still formed in the reference's
-                // order (the even lane multiplies its factors, hands the partial product to the odd lane, which
-                // multiplies its own on top and hands the result back).
-                int c0 = 0;
-                for (; c0 + kWave <= t.m || t.m - c0 > kWave / 2; c0 += kWave) {
-                    const int c = c0 + lane;
-                    if (c < t.m) {
-                        double* row = msg + c * MAXR;
-                        double tt[MAXR];
-#pragma unroll
-                        for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + row[j]) - 1;
-                        double product = 1.0;
-#pragma unroll
-                        for (int j = 0; j < MAXR; j++) product = product * tt[j];
-                        const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
-#pragma unroll
-                        for (int j = 0; j < MAXR; j++) {
-                            const double prd = product / tt[j];
-                            const double val = (1 - prd) / (1 + prd);
-                            row[j] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
-                        }
-                    }
-                }
-                if (c0 < t.m) {
-                    constexpr int HR = MAXR / 2;
-                    const int c = c0 + (lane >> 1);
-                    const bool upper = lane & 1;
-                    const bool valid = c < t.m;
-                    double* row = msg + (valid ? c : 0) * MAXR + (upper ? HR : 0);
-                    double tt[HR];
-#pragma unroll
-                    for (int j = 0; j < HR; j++) tt[j] = 2 / (1 + row[j]) - 1;
-                    double part = 1.0;
-#pragma unroll
-                    for (int j = 0; j < HR; j++) part = part * tt[j];             // even lane: ((1 t0) t1) t2
-                    double product = __shfl_xor(part, 1);                         // odd lane: the even lane's partial
-#pragma unroll
-                    for (int j = 0; j < HR; j++) product = product * tt[j];       // odd lane: ... t3) t4) t5
-                    const double back = __shfl_xor(product, 1);                   // even lane: the finished product
-                    if (!upper) product = back;
-                    const int deg = ROWS_FULL ? MAXR : int(chk_deg[valid ? c : 0]);
-                    if (valid) {
-#pragma unroll
-                        for (int j = 0; j < HR; j++) {
-                            const double prd = product / tt[j];
-                            const double val = (1 - prd) / (1 + prd);
-                            row[j] = (ROWS_FULL || (upper ? HR : 0) + j < deg) ? val : 0.0;
-                        }
-                    }
-                }
+                if (nit == 1) check_phase(std::true_type{});
+                else check_phase(std::false_type{});
                 wave_sync();
                 // ---- update_vars + decision: lane == variable node
                 for (int v = lane; v < t.n; v += kWave) {
