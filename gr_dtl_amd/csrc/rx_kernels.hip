@@ -139,31 +139,46 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
             __syncthreads();
         }
     };
-    // mixed[i] = r[i - (N+cp)] * osc[i]; sample s of symbol sym sits at stream index i = trigger + sym*P + cp + s
+    // mixed[i] = r[i - (N+cp)] * osc[i]; sample s of symbol sym sits at stream index i = trigger + sym*P + cp + s.
+    // The loads carry no branch (address clamped into the stream, value zeroed afterwards): all of a lane's samples
+    // and row positions are requested before the first one is waited for -- with a bounds test around each load the
+    // compiler serialised them, one exposed memory latency per sample.
     if (wave_local) {
         if (active) {
             const int64_t i0 = trigger + int64_t(sym0 + u) * P + t.cp_len;
             cf32 v[4];
+            int br[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int64_t src = i0 + (q + j * (N >> 2)) - P;
-                v[j] = cf32{ 0.0f, 0.0f };
-                if (src >= 0 && src < n_samples) v[j] = iq[src];
+                const int sidx = q + j * (N >> 2);
+                const int64_t src = i0 + sidx - P;
+                const bool inside = src >= 0 && src < n_samples;
+                const cf32 val = iq[inside ? src : 0];
+                br[j] = t.bitrev[sidx];               // bit-reversed and swizzled
+                v[j] = cf32{ inside ? val.re : 0.0f, inside ? val.im : 0.0f };
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int sidx = q + j * (N >> 2);
-                x[t.bitrev[sidx]] = ABL == 1 ? v[j] : cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
+                x[br[j]] = ABL == 1 ? v[j] : cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
             }
         }
     } else {
         const int br = t.bitrev[tid];                 // bit-reversed and swizzled
-        for (int uu = 0; uu < n_sym; uu++) {
-            const int64_t i = trigger + int64_t(sym0 + uu) * P + t.cp_len + tid;
-            const int64_t src = i - P;
-            cf32 v = { 0.0f, 0.0f };
-            if (src >= 0 && src < n_samples) v = iq[src];
-            buf[uu * N + br] = cmul(v, expj(osc_phase(segs, n_segs, seg, i, sens)));
+        cf32 v[4];
+#pragma unroll
+        for (int uu = 0; uu < 4; uu++) {
+            const int64_t src = trigger + int64_t(sym0 + uu) * P + t.cp_len + tid - P;
+            const bool inside = uu < n_sym && src >= 0 && src < n_samples;
+            const cf32 val = iq[inside ? src : 0];
+            v[uu] = cf32{ inside ? val.re : 0.0f, inside ? val.im : 0.0f };
+        }
+#pragma unroll
+        for (int uu = 0; uu < 4; uu++) {
+            if (uu < n_sym) {
+                const int64_t i = trigger + int64_t(sym0 + uu) * P + t.cp_len + tid;
+                buf[uu * N + br] = cmul(v[uu], expj(osc_phase(segs, n_segs, seg, i, sens)));
+            }
         }
     }
     sync_stage();
@@ -258,6 +273,7 @@ __device__ uint32_t crc_bits(const uint8_t* data, int len, int nbits, uint32_t p
 // B = the rounding boundary between thr and its predecessor (25 significant bits), num >= B * den
 // is exact in double (49-bit product) and decides the same way for every finite den > 0.
 // ------------------------------------------------------------------------------------------
+constexpr int kEqRecipLds = 258;               // frame equaliser: reciprocals of a lane's pilot sample count (<= L + 1)
 constexpr int kSyncTile = kSyncTileSamples;   // the stream carry is aligned to the sync tile
 
 // strip length R (outputs per thread): 8 with 512 threads for N <= 512 (half the registers per thread, twice the
@@ -705,7 +721,7 @@ __device__ __forceinline__ Welford welford_merge(Welford a, Welford b, const dou
 // source is always column (k + off) mod N of row i + lag with ONE lag in {-1, 0, +1}: the lane walks the
 // source rows in order and equalises destination symbol (row - lag); the zero symbol comes first (lag -1)
 // or last (lag +1).
-__global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
+__global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
                                 const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
                                 int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
                                 cf32* __restrict__ eq_hard, cf32* __restrict__ eq_soft,
@@ -744,7 +760,25 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
         for (int ps = 0; ps < t.n_pilot_sets; ps++) pilot_bits |= (t.pilot_mask[ps * N + k] ? 1u : 0u) << ps;
     Welford w = { 0.0, 0.0, 0.0 };
     const double* __restrict__ recip = t.recip_count;
+    // A step must not wait for global memory: what it needs from the configuration tables is either constant per
+    // lane (kept in registers: serializer rank / length for the usual single carrier set), small (the reciprocals of
+    // a lane's own sample count, at most L + 1 of them: LDS) or known one step ahead (the pilot value, and rank /
+    // length when the carrier sets rotate: requested during the previous step).  The three set indices advance by
+    // one per symbol and wrap: counters, not modulo operations.
+    __shared__ double s_recip[kEqRecipLds];
+    const bool recip_in_lds = L + 2 <= kEqRecipLds;
+    if (recip_in_lds)
+        for (int e = tid; e < L + 2; e += blockDim.x) s_recip[e] = recip[e];
     int pilot_carr_set = t.n_pilot_sets ? h % t.n_pilot_sets : 0;
+    int pset = h % t.n_pilot_sym_sets;                // pilot symbol set of destination symbol 0
+    int oset = 1 % t.n_occ_sets;                      // ofdm_serializer_vcc: symbols_skipped = 1
+    const bool one_occ_set = t.n_occ_sets == 1;
+    int occ_r = t.occ_rank[oset * N + k], occ_n = t.occ_len[oset];   // of the step about to run
+    auto pilot_here = [&](int set) -> bool {
+        return t.n_pilot_sets && (pilot_bits_ok ? ((pilot_bits >> set) & 1u) != 0 : t.pilot_mask[set * N + k] != 0);
+    };
+    cf32 pilot_next = { 0.0f, 0.0f };                 // pilot value of the step about to run
+    if (pilot_here(pilot_carr_set)) pilot_next = t.pilot_val[pset * N + k];
     cf32* hard_row = eq_hard ? eq_hard + size_t(blockIdx.x) * total : nullptr;
     cf32* soft_row = eq_soft ? eq_soft + size_t(blockIdx.x) * total : nullptr;
     cf32* soft_out = soft_syms + size_t(blockIdx.x) * t.frame_capacity;
@@ -752,11 +786,17 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
 
     // frame_equalize for destination symbol i of this carrier (ofdm_adaptive_equalizer.cc:217-268)
     auto eq_step = [&](int i, cf32 y) {
-        const int pset = (h + i) % t.n_pilot_sym_sets;
-        const bool is_pilot = t.n_pilot_sets && (pilot_bits_ok ? ((pilot_bits >> pilot_carr_set) & 1u) != 0
-                                                              : t.pilot_mask[pilot_carr_set * N + k] != 0);
-        cf32 pilot_ref = { 0.0f, 0.0f };
-        if (is_pilot) pilot_ref = t.pilot_val[pset * N + k];
+        const bool is_pilot = pilot_here(pilot_carr_set);
+        const cf32 pilot_ref = pilot_next;
+        const int r = occ_r, n_data = occ_n;
+        // next step's table entries: requested now, used then
+        const int pset_n = pset + 1 == t.n_pilot_sym_sets ? 0 : pset + 1;
+        const int pcs_n = t.n_pilot_sets ? (pilot_carr_set + 1 == t.n_pilot_sets ? 0 : pilot_carr_set + 1) : 0;
+        const int oset_n = oset + 1 == t.n_occ_sets ? 0 : oset + 1;
+        if (i + 1 < L) {
+            if (pilot_here(pcs_n)) pilot_next = t.pilot_val[pset_n * N + k];
+            if (!one_occ_set) { occ_r = t.occ_rank[oset_n * N + k]; occ_n = t.occ_len[oset_n]; }
+        }
         cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
         // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
         // tap towards y / (known or decided symbol) -- so the two cases share one pair of complex divisions
@@ -774,7 +814,7 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
                 const double x = double(sqrtf(eqv.re * eqv.re + eqv.im * eqv.im));
                 w.n += 1.0;
                 const double d = x - w.mean;
-                w.mean += dm_div_by_count(d, w.n, recip[int(w.n)]);
+                w.mean += dm_div_by_count(d, w.n, recip_in_lds ? s_recip[int(w.n)] : recip[int(w.n)]);
                 w.m2 += d * (x - w.mean);
             } else {
                 unsigned idx;
@@ -796,11 +836,9 @@ __global__ void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t
         if (hard_row) hard_row[i * N + k] = hard_v;
         if (soft_row) soft_row[i * N + k] = soft_v;
         // ofdm_serializer_vcc (symbols_skipped = 1): data carrier r of OFDM symbol i is symbol q_base + r
-        const int set = (1 + i) % t.n_occ_sets;
-        const int r = t.occ_rank[set * N + k];
         if (r >= 0 && q_base + r < fd.n_syms) soft_out[q_base + r] = soft_v;
-        q_base += t.occ_len[set];
-        if (t.n_pilot_sets) pilot_carr_set = (pilot_carr_set + 1) % t.n_pilot_sets;
+        q_base += n_data;
+        pset = pset_n; pilot_carr_set = pcs_n; oset = oset_n;
     };
 
     __syncthreads();                                  // s_pts, tw
