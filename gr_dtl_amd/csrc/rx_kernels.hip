@@ -787,16 +787,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     // frame_equalize for destination symbol i of this carrier (ofdm_adaptive_equalizer.cc:217-268)
     auto eq_step = [&](int i, cf32 y) {
         const bool is_pilot = pilot_here(pilot_carr_set);
-        const cf32 pilot_ref = pilot_next;
-        const int r = occ_r, n_data = occ_n;
-        // next step's table entries: requested now, used then
-        const int pset_n = pset + 1 == t.n_pilot_sym_sets ? 0 : pset + 1;
-        const int pcs_n = t.n_pilot_sets ? (pilot_carr_set + 1 == t.n_pilot_sets ? 0 : pilot_carr_set + 1) : 0;
-        const int oset_n = oset + 1 == t.n_occ_sets ? 0 : oset + 1;
-        if (i + 1 < L) {
-            if (pilot_here(pcs_n)) pilot_next = t.pilot_val[pset_n * N + k];
-            if (!one_occ_set) { occ_r = t.occ_rank[oset_n * N + k]; occ_n = t.occ_len[oset_n]; }
-        }
         cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
         // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
         // tap towards y / (known or decided symbol) -- so the two cases share one pair of complex divisions
@@ -809,12 +799,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
             const cf32 eqv = cdiv(y, Hk);
             cf32 ref;
             if (is_pilot) {
-                ref = pilot_ref;
+                ref = pilot_next;                     // requested at the end of the previous step
                 // mpsk_snr_est_simple::update on |pilot_eq| (Welford, double)
                 const double x = double(sqrtf(eqv.re * eqv.re + eqv.im * eqv.im));
                 w.n += 1.0;
                 const double d = x - w.mean;
-                w.mean += dm_div_by_count(d, w.n, recip_in_lds ? s_recip[int(w.n)] : recip[int(w.n)]);
+                // the table is in LDS (a pointer chosen at run time between LDS and global memory would become a flat
+                // load, whose wait also drains the loads requested for the next step); frames too long for it divide
+                double rc;
+                if (recip_in_lds) rc = s_recip[int(w.n)];
+                else rc = 1.0 / w.n;
+                w.mean += dm_div_by_count(d, w.n, rc);
                 w.m2 += d * (x - w.mean);
             } else {
                 unsigned idx;
@@ -836,9 +831,18 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
         if (hard_row) hard_row[i * N + k] = hard_v;
         if (soft_row) soft_row[i * N + k] = soft_v;
         // ofdm_serializer_vcc (symbols_skipped = 1): data carrier r of OFDM symbol i is symbol q_base + r
-        if (r >= 0 && q_base + r < fd.n_syms) soft_out[q_base + r] = soft_v;
-        q_base += n_data;
-        pset = pset_n; pilot_carr_set = pcs_n; oset = oset_n;
+        if (occ_r >= 0 && q_base + occ_r < fd.n_syms) soft_out[q_base + occ_r] = soft_v;
+        q_base += occ_n;
+        // next step's table entries: requested last (behind this step's stores: on this hardware loads and stores
+        // complete in one queue, so whoever waits for a load also waits for every store issued before it) and first
+        // looked at after the next step's first division
+        pset = pset + 1 == t.n_pilot_sym_sets ? 0 : pset + 1;
+        pilot_carr_set = t.n_pilot_sets ? (pilot_carr_set + 1 == t.n_pilot_sets ? 0 : pilot_carr_set + 1) : 0;
+        oset = oset + 1 == t.n_occ_sets ? 0 : oset + 1;
+        if (i + 1 < L) {
+            if (pilot_here(pilot_carr_set)) pilot_next = t.pilot_val[pset * N + k];
+            if (!one_occ_set) { occ_r = t.occ_rank[oset * N + k]; occ_n = t.occ_len[oset]; }
+        }
     };
 
     __syncthreads();                                  // s_pts, tw
