@@ -307,11 +307,26 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     __shared__ unsigned char last_flag[kSyncThreads];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
-    for (int q = tid; q < n_raw; q += kSyncThreads) {
-        const int64_t j = b0 + q;
-        cf32 v = { 0.0f, 0.0f };
-        if (j >= 0 && j < n) v = iq[j];
-        raw[sync_pad<R>(q)] = v;
+    // Staging: every load of the thread is requested before the first one is waited for (addresses clamped into the
+    // stream, values zeroed afterwards -- a bounds test around the load made the compiler run the loop as load, wait,
+    // store, load, ...: one exposed memory latency per 512 samples of the tile).
+    {
+        constexpr int kTileIters = R;                                  // kSyncTile / kSyncThreads
+        constexpr int kHistIters = R == 8 ? 2 : 6;                     // (N + N/2) / kSyncThreads for the largest N served
+        cf32 stage[kTileIters + kHistIters];
+#pragma unroll
+        for (int it = 0; it < kTileIters + kHistIters; it++) {
+            const int q = tid + it * kSyncThreads;
+            const int64_t j = b0 + q;
+            const bool inside = q < n_raw && j >= 0 && j < n;
+            const cf32 v = iq[inside ? j : 0];
+            stage[it] = cf32{ inside ? v.re : 0.0f, inside ? v.im : 0.0f };
+        }
+#pragma unroll
+        for (int it = 0; it < kTileIters + kHistIters; it++) {
+            const int q = tid + it * kSyncThreads;
+            if (q < n_raw) raw[sync_pad<R>(q)] = stage[it];
+        }
     }
     __syncthreads();
 

@@ -13,7 +13,7 @@ for A in "$@"; do
 import csv, glob, sys
 for p in glob.glob('/tmp/abl_%s/**/*kernel_stats.csv' % sys.argv[1], recursive=True):
     for r in csv.DictReader(open(p)):
-        if any(k in r["Name"] for k in ("frame_eq", "demap_kernel", "header_kernel", "ldpc_bp_np", "sync_edges")):
+        if any(k in r["Name"] for k in ("frame_eq", "demap_kernel", "header_kernel", "ldpc_bp_np", "sync_edges", "tb_check")):
             print("   %-28s calls %4s avg %9.1f us" % (r["Name"].split("(")[0][-28:], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
