@@ -325,6 +325,11 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     Meta mcur{ 0, 0 }, mnxt{ 0, 0 };
     int cw = advance();
     if (cw < ncw) fetch(cw, cur, mcur);
+    // The first codeword's soft bits are waited for HERE.  Without this the compiler has to assume, inside the loop,
+    // that loads into `cur` may still be in flight (true only on the first pass) and -- loads being counted in one
+    // in-order queue -- drains the queue at the first LDS read of every codeword, i.e. waits for the prefetch of the
+    // NEXT codeword it has just issued instead of decoding under it.
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     while (cw < ncw) {
         const int cw_next = advance();
         if (cw_next < ncw) fetch(cw_next, nxt, mnxt);
