@@ -736,6 +736,12 @@ __device__ __forceinline__ Welford welford_merge(Welford a, Welford b, const dou
 // source is always column (k + off) mod N of row i + lag with ONE lag in {-1, 0, +1}: the lane walks the
 // source rows in order and equalises destination symbol (row - lag); the zero symbol comes first (lag -1)
 // or last (lag +1).
+// STAGED (the usual configuration: one data-carrier set, at most 32 pilot-carrier sets, no eq_hard / eq_soft rows
+// requested): an equaliser step touches no global memory at all -- the pilot values of a batch's steps are fetched
+// into LDS before the batch, the equalised data symbols are parked in LDS and stored after it.  The general form
+// requests its table entries one step ahead and stores from inside the step; the compiler then drains the memory
+// queue once per step (loads and stores share one in-order counter), the staged form once per batch.
+template <bool STAGED>
 __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
                                 const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
                                 int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
@@ -747,6 +753,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // 4 x N : FFT scratch (four symbols per batch)
     Welford* wred = reinterpret_cast<Welford*>(buf + 4 * N); // blockDim/64 partials
     cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64); // N per-pass twiddles
+    [[maybe_unused]] cf32* st_soft = tw + N;          // STAGED: 4 x N data symbols of the running batch (lane k: column k)
+    [[maybe_unused]] cf32* st_pil = st_soft + 4 * N;  // STAGED: 4 x N pilot values of the lane's next four steps
     tw[tid] = t.twiddle[tid];
 
     const FrameDesc fd = frames[blockIdx.x];
@@ -793,15 +801,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
         return t.n_pilot_sets && (pilot_bits_ok ? ((pilot_bits >> set) & 1u) != 0 : t.pilot_mask[set * N + k] != 0);
     };
     cf32 pilot_next = { 0.0f, 0.0f };                 // pilot value of the step about to run
-    if (pilot_here(pilot_carr_set)) pilot_next = t.pilot_val[pset * N + k];
+    if (!STAGED && pilot_here(pilot_carr_set)) pilot_next = t.pilot_val[pset * N + k];
     cf32* hard_row = eq_hard ? eq_hard + size_t(blockIdx.x) * total : nullptr;
     cf32* soft_row = eq_soft ? eq_soft + size_t(blockIdx.x) * total : nullptr;
     cf32* soft_out = soft_syms + size_t(blockIdx.x) * t.frame_capacity;
     int q_base = 0;                                   // data symbols in front of destination symbol i (serializer order)
+    [[maybe_unused]] int staged = 0, staged_base = 0; // STAGED: steps run since stage_begin, q_base at stage_begin
 
     // frame_equalize for destination symbol i of this carrier (ofdm_adaptive_equalizer.cc:217-268)
     auto eq_step = [&](int i, cf32 y) {
-        const bool is_pilot = pilot_here(pilot_carr_set);
+        const bool is_pilot = STAGED ? (t.n_pilot_sets && ((pilot_bits >> pilot_carr_set) & 1u) != 0) : pilot_here(pilot_carr_set);
         cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
         // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
         // tap towards y / (known or decided symbol) -- so the two cases share one pair of complex divisions
@@ -814,7 +823,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
             const cf32 eqv = cdiv(y, Hk);
             cf32 ref;
             if (is_pilot) {
-                ref = pilot_next;                     // requested at the end of the previous step
+                if (STAGED) ref = st_pil[staged * N + k];
+                else ref = pilot_next;                // requested at the end of the previous step
                 // mpsk_snr_est_simple::update on |pilot_eq| (Welford, double)
                 const double x = double(sqrtf(eqv.re * eqv.re + eqv.im * eqv.im));
                 w.n += 1.0;
@@ -843,6 +853,14 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
             Hk = cadd(cscale(alpha, Hk), cdiv(cscale(1 - alpha, y), ref));
             hard_v = ref;
         }
+        if (STAGED) {
+            st_soft[staged * N + k] = soft_v;         // stored by stage_end
+            staged++;
+            q_base += occ_n;
+            pset = pset + 1 == t.n_pilot_sym_sets ? 0 : pset + 1;
+            pilot_carr_set = t.n_pilot_sets ? (pilot_carr_set + 1 == t.n_pilot_sets ? 0 : pilot_carr_set + 1) : 0;
+            return;
+        }
         if (hard_row) hard_row[i * N + k] = hard_v;
         if (soft_row) soft_row[i * N + k] = soft_v;
         // ofdm_serializer_vcc (symbols_skipped = 1): data carrier r of OFDM symbol i is symbol q_base + r
@@ -860,11 +878,40 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
         }
     };
 
+    // STAGED: pilot values of the lane's next four steps (loads without a branch between them: one wait for all)
+    auto stage_begin = [&]() {
+        if (!STAGED) return;
+        staged = 0;
+        staged_base = q_base;
+        if (pilot_bits) {
+            int ps = pset;
+            cf32 pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                pv[u] = t.pilot_val[ps * N + k];
+                ps = ps + 1 == t.n_pilot_sym_sets ? 0 : ps + 1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) st_pil[u * N + k] = pv[u];
+        }
+    };
+    // STAGED: the data symbols of the steps just run, in serializer order (symbols_skipped = 1: data carrier r of the
+    // u-th of these steps is symbol staged_base + u occ_n + r)
+    auto stage_end = [&]() {
+        if (!STAGED) return;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = staged_base + u * occ_n + occ_r;
+            if (u < staged && occ_r >= 0 && idx < fd.n_syms) soft_out[idx] = st_soft[u * N + k];
+        }
+    };
+
     __syncthreads();                                  // s_pts, tw
-    if (lag < 0) eq_step(0, cf32{ 0.0f, 0.0f });      // its source would be row -1: the zero fill of the shift
+    if (lag < 0) { stage_begin(); eq_step(0, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row -1: the zero fill of the shift
     for (int i0 = 0; i0 < L; i0 += 4) {
         const int nb = min(4, L - i0);
         load_and_fft4<DTL_ABLATE>(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
+        stage_begin();
         for (int u = 0; u < nb; u++) {
             const int i = i0 + u - lag;               // destination symbol fed by source row i0 + u
             if (i >= 0 && i < L) {
@@ -875,9 +922,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
                 eq_step(i, cmul(v, pc));
             }
         }
+        stage_end();
         __syncthreads();                              // the next batch overwrites the scratch rows
     }
-    if (lag > 0) eq_step(L - 1, cf32{ 0.0f, 0.0f });  // its source would be row L
+    if (lag > 0) { stage_begin(); eq_step(L - 1, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row L
 
     // combine the per-carrier Welford states (Chan); double, fixed tree order
     for (int o = 32; o > 0; o >>= 1) {
@@ -1301,12 +1349,15 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
     return DTL_OK;
 }
 
-size_t payload_lds_bytes(const RxTables& t)
+static size_t frame_eq_lds_bytes(const RxTables& t, bool staged)
 {
     size_t b = size_t(4 * t.fft_len) * sizeof(cf32) + size_t((t.fft_len + 63) / 64) * sizeof(Welford) +
                size_t(t.fft_len) * sizeof(cf32);
+    if (staged) b += size_t(8 * t.fft_len) * sizeof(cf32); // two 4 x N arrays: parked data symbols, pilot values
     return (b + 15) & ~size_t(15);
 }
+
+size_t payload_lds_bytes(const RxTables& t) { return frame_eq_lds_bytes(t, false); }
 
 // phase B: frame equaliser (FFT + decision-directed one-tap equaliser + SNR estimate) -> soft demapper (FEC) or
 // hard demapper + packer + CRC (no FEC); the equalised data symbols are handed over in `soft_syms` (n_frames x capacity)
@@ -1317,10 +1368,17 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
 {
     if (n_frames <= 0) return DTL_OK;
     if (!soft_syms) { set_last_error("payload: no buffer for the equalised symbols"); return DTL_ERR_INVALID_ARG; }
-    const size_t lds = payload_lds_bytes(t);
+    // the staged form (no global memory inside an equaliser step) serves the usual configuration when its LDS fits
+    const bool staged = t.n_occ_sets == 1 && t.n_pilot_sets <= 32 && !eq_hard && !eq_soft &&
+                        frame_eq_lds_bytes(t, true) <= 64 * 1024;
+    const size_t lds = frame_eq_lds_bytes(t, staged);
     if (lds > 64 * 1024) { set_last_error("payload kernel: FFT scratch does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(frame_eq_kernel, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
-                       stats, eq_hard, eq_soft, soft_syms);
+    if (staged)
+        hipLaunchKernelGGL(frame_eq_kernel<true>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
+                           stats, eq_hard, eq_soft, soft_syms);
+    else
+        hipLaunchKernelGGL(frame_eq_kernel<false>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
+                           stats, eq_hard, eq_soft, soft_syms);
     if (t.has_fec) {
         const dim3 grid(n_frames, (t.frame_capacity + 255) / 256);
         if (t.llr_dist_mode) hipLaunchKernelGGL(demap_kernel<true>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
