@@ -715,12 +715,17 @@ struct Welford {
 };
 
 // recip[k] = RN(1 / k): the counts are small integers, so their divisions take the table form (dm_div_by_count)
-__device__ __forceinline__ Welford welford_merge(Welford a, Welford b, const double* __restrict__ recip)
+// (the frame equaliser passes an LDS copy of the table's first `n_lds` entries: a global load in every level of its
+// merge tree would be a memory latency each)
+__device__ __forceinline__ Welford welford_merge(Welford a, Welford b, const double* __restrict__ recip,
+                                                 const double* recip_lds = nullptr, int n_lds = 0)
 {
     if (b.n == 0) return a;
     if (a.n == 0) return b;
     const double n = a.n + b.n, d = b.mean - a.mean;
-    const double r = recip[int(n)];
+    double r;
+    if (int(n) < n_lds) r = recip_lds[int(n)];
+    else r = recip[int(n)];
     return { n, a.mean + d * dm_div_by_count(b.n, n, r), a.m2 + b.m2 + d * d * dm_div_by_count(a.n * b.n, n, r) };
 }
 
@@ -927,16 +932,28 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     }
     if (lag > 0) { stage_begin(); eq_step(L - 1, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row L
 
-    // combine the per-carrier Welford states (Chan); double, fixed tree order
+    // combine the per-carrier Welford states (Chan); double, fixed tree order.  The reciprocals of the merged counts
+    // (at most L x pilots-per-set of them) go to the FFT scratch first, which is free now.
+    double* mrec = reinterpret_cast<double*>(buf);
+    const int n_mrec = min(L * t.n_pilots + 2, 4 * N);
+    {
+        double rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) rv[j] = recip[min(tid + j * int(blockDim.x), n_mrec - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (tid + j * int(blockDim.x) < n_mrec) mrec[tid + j * int(blockDim.x)] = rv[j];
+    }
+    __syncthreads();
     for (int o = 32; o > 0; o >>= 1) {
         Welford other = { __shfl_down(w.n, o), __shfl_down(w.mean, o), __shfl_down(w.m2, o) };
-        w = welford_merge(w, other, recip);
+        w = welford_merge(w, other, recip, mrec, n_mrec);
     }
     if ((tid & 63) == 0) wred[tid >> 6] = w;
     __syncthreads();
     if (tid == 0) {
         Welford a = wred[0];
-        for (int i = 1; i < int(blockDim.x + 63) / 64; i++) a = welford_merge(a, wred[i], recip);
+        for (int i = 1; i < int(blockDim.x + 63) / 64; i++) a = welford_merge(a, wred[i], recip, mrec, n_mrec);
         // mpsk_snr_est_simple::snr()/noise(); get_noise() (equalizer.cc:279-287)
         const double signal_db = 10.0 * log10(fabs(a.mean * a.mean));
         const double noise_db = 10.0 * log10(2.0 * a.m2 / a.n);
