@@ -1076,16 +1076,33 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
         for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
         T[i] = c;
     }
-    for (int i = lane; i < 16 * 32; i += 64) zmat[i] = zmat_g[i];
+    {   // loads in groups without a branch between them: one memory latency per group, not per load
+        uint32_t z[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) z[j] = zmat_g[lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) zmat[lane + 64 * j] = z[j];
+    }
     const TbDesc d = tbs[tb];
     uint8_t* bytes = staging + size_t(tb) * stride;
     const int n_bytes = int(d.n_bits / 8);
-    for (int b = lane; b < n_bytes; b += 64) {
-        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(bits + size_t(d.bits_off) + size_t(b) * 8);
-        // repack(1,8) LSB first: bit j of the byte is the LSB of input byte j
-        const unsigned v = unsigned(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
-        bytes_l[b] = uint8_t(v);
-        bytes[b] = uint8_t(v);
+    for (int b0 = lane; b0 < n_bytes; b0 += 64 * 4) {
+        unsigned long long w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = min(b0 + 64 * j, n_bytes - 1);
+            w[j] = *reinterpret_cast<const unsigned long long*>(bits + size_t(d.bits_off) + size_t(b) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = b0 + 64 * j;
+            if (b < n_bytes) {
+                // repack(1,8) LSB first: bit j of the byte is the LSB of input byte j
+                const unsigned v = unsigned(((w[j] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+                bytes_l[b] = uint8_t(v);
+                bytes[b] = uint8_t(v);
+            }
+        }
     }
     int it_sum = 0;
     for (unsigned c = lane; c < d.n_cw; c += 64) it_sum += nit[d.cw_first + c];
