@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     __syncthreads();
 
     // ---- pass A: strip totals.  Sample j of the strip domain (which starts at t0 - N) is raw[half + j].
-    float cr[R], ci[R], eh[R];
+    // (the energy terms are formed again in pass C from the staged sample -- one more LDS read per output -- rather
+    // than held: R more live registers here meant spills to scratch, i.e. memory round trips, at 80 VGPRs)
+    float cr[R], ci[R];
     double tr = 0, ti = 0, te = 0;
     {
         const int base = half + (nh + tid) * R;
@@ -340,8 +342,8 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
             const cf32 a = raw[sync_pad<R>(base + s)], b = raw[sync_pad<R>(base + s - half)];
             cr[s] = a.re * b.re + a.im * b.im;
             ci[s] = a.im * b.re - a.re * b.im;
-            eh[s] = 0.5f * (a.re * a.re + a.im * a.im);
-            tr += double(cr[s]); ti += double(ci[s]); te += double(eh[s]);
+            const float e = 0.5f * (a.re * a.re + a.im * a.im);
+            tr += double(cr[s]); ti += double(ci[s]); te += double(e);
         }
     }
     double hr = 0, hi = 0, he = 0; // history strip `tid` (wave 0 only: nh <= 64)
@@ -408,11 +410,13 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
 #pragma unroll
     for (int s = 0; s < R; s++) {
         const cf32 oa = raw[sync_pad<R>(rb_new + s - half)], ob = raw[sync_pad<R>(rb_new + s - N)];
+        const cf32 na = raw[sync_pad<R>(rb_new + s)];
         const float ocr = oa.re * ob.re + oa.im * ob.im, oci = oa.im * ob.re - oa.re * ob.im;
         const float oeh = 0.5f * (ob.re * ob.re + ob.im * ob.im);
+        const float neh = 0.5f * (na.re * na.re + na.im * na.im);
         Wr = (Wr + double(cr[s])) - double(ocr);
         Wi = (Wi + double(ci[s])) - double(oci);
-        We = (We + double(eh[s])) - double(oeh);
+        We = (We + double(neh)) - double(oeh);
         float num, den;
         metric_parts(num, den);
         if (WITH_METRIC) {
