@@ -1241,7 +1241,8 @@ int Receiver::stage_frames(Call& c)
         if (llr_total + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
         fdesc.push_back(d);
         frames.push_back(fi);
-        ss.demux_pos = trig + int64_t(hdr_syms + L) * P;
+        // header_payload_demux consumes all but the LAST payload item: it may hold the next trigger
+        ss.demux_pos = trig + int64_t(hdr_syms + L) * P - 1;
     }
     DTL_TRY(flush_payload());
     if (!n_cand) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }

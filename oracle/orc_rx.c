@@ -134,7 +134,9 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
         if (o->eq_hard) memcpy(&o->eq_hard[(size_t)fi * L * N], hard, (size_t)L * N * sizeof(orc_c32));
         if (o->eq_soft) memcpy(&o->eq_soft[(size_t)fi * L * N], soft, (size_t)L * N * sizeof(orc_c32));
         o->n_frames++;
-        pos = i + (long)(hdr_syms + L) * P;
+        /* GR3.10 header_payload_demux_impl::general_work, STATE_PAYLOAD: "consume payload, except for the
+         * last item" (it may hold the next trigger): consume_each(payload_len * (N + gi) - 1) */
+        pos = i + (long)(hdr_syms + L) * P - 1;
         if (hdr.payload_len == 0) continue; /* work() returns 0: empty frame dropped (:218,254) */
 
         /* ofdm_serializer_vcc(..., packet_length key, symbols_skipped = 1) on the soft output */
