@@ -116,6 +116,23 @@ def cpu_baseline(cfg, w, x_host, n_frames_sample, frame_samples, cores):
                        "%d frames decoded" % (n_frames_sample, n_samples, cores, dt, dt * cores, decoded))
 
 
+def launch_ranks(n, argv):
+    """One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py argv`, rendezvous on
+    127.0.0.1 at a free port.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +147,16 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (default: all, at most 16)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent never touches
+        # HIP (no torch import, no device query): the ranks are children of torch.distributed.run, their stdout
+        # (rank 0's ONE JSON line) is ours.
+        return launch_ranks(args.gpus, sys.argv[1:])
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s; launch with --nproc-per-node equal to --gpus "
+                         "(or without a launcher: bench.py starts the ranks itself)"
+                         % (args.gpus, os.environ.get("WORLD_SIZE", "unset")))
 
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on fd 1) and any
     # stray print are sent to stderr; the result goes to the saved descriptor at the end
@@ -287,4 +314,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    rc = main()
+    sys.exit(rc if isinstance(rc, int) else 0)

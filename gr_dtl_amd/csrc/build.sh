@@ -10,7 +10,8 @@ mkdir -p "${HERE}/_obj"
 OBJS=()
 for s in "${SRCS[@]}"; do
   o="${HERE}/_obj/$(basename "$s").o"
-  if [[ ! -f "$o" || "$s" -nt "$o" || -n "$(find "${HERE}" -maxdepth 1 -name '*.h' -newer "$o" -print -quit)" ]]; then
+  # headers: the kernels' own (csrc/*.h) and the ABI structs / status codes (include/*.h, *.hpp)
+  if [[ ! -f "$o" || "$s" -nt "$o" || -n "$(find "${HERE}" "${HERE}/../../include" -maxdepth 1 \( -name '*.h' -o -name '*.hpp' \) -newer "$o" -print -quit)" ]]; then
     "${HIPCC}" "${FLAGS[@]/-shared/}" -x hip -c "$s" -o "$o" ${EXTRA_HIPCC_FLAGS:-}
   fi
   OBJS+=("$o")

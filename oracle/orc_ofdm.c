@@ -24,6 +24,25 @@ typedef float complex cf;
 static inline cf to_cf(orc_c32 v) { return v.re + v.im * I; }
 static inline orc_c32 from_cf(cf v) { return (orc_c32){ crealf(v), cimagf(v) }; }
 
+/* (a+ib)/(c+id) in float: Smith's algorithm written out, operation by operation -- what libgcc's __divsc3 computes
+ * for finite operands up to GCC 11.  The C operator is NOT used: from GCC 12 on it evaluates float complex division
+ * in double, and the result bits would depend on the compiler the oracle is built with. */
+static inline cf cdiv(cf x, cf y)
+{
+    const float a = crealf(x), b = cimagf(x), c = crealf(y), d = cimagf(y);
+    float re, im;
+    if (fabsf(c) < fabsf(d)) {
+        const float ratio = c / d, denom = (c * ratio) + d;
+        re = ((a * ratio) + b) / denom;
+        im = ((b * ratio) - a) / denom;
+    } else {
+        const float ratio = d / c, denom = (d * ratio) + c;
+        re = ((b * ratio) + a) / denom;
+        im = (b - (a * ratio)) / denom;
+    }
+    return re + im * I;
+}
+
 /* carrier index (may be negative) -> position in a shifted FFT vector (DC at N/2) */
 static inline int shifted_index(int carrier, int N)
 {
@@ -287,7 +306,7 @@ int orc_chanest(const orc_cfg* cfg, const orc_c32* sync_syms, orc_c32* taps)
     cf* corr_v = (cf*)calloc(N, sizeof(cf));
     for (int i = 0; i < N; i++) {
         if (s1[i].re == 0 && s1[i].im == 0) corr_v[i] = 0;
-        else corr_v[i] = to_cf(cfg->sync2[i]) / to_cf(s1[i]);
+        else corr_v[i] = cdiv(to_cf(cfg->sync2[i]), to_cf(s1[i]));
     }
     const orc_c32* y1 = sync_syms;
     const orc_c32* y2 = sync_syms + N;
@@ -308,7 +327,7 @@ int orc_chanest(const orc_cfg* cfg, const orc_c32* sync_syms, orc_c32* taps)
     else if (carr_offset < 0) loop_end = N + carr_offset;
     for (int i = loop_start; i < loop_end; i++)
         if (ref[i - carr_offset].re != 0 || ref[i - carr_offset].im != 0)
-            taps[i - carr_offset] = from_cf(to_cf(y2[i]) / to_cf(ref[i - carr_offset]));
+            taps[i - carr_offset] = from_cf(cdiv(to_cf(y2[i]), to_cf(ref[i - carr_offset])));
     free(corr_v);
     return carr_offset;
 }
@@ -370,19 +389,19 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
             if (!occupied[k] && !is_pilot) continue;
             long p = (long)i * N + k;
             if (is_pilot) {
-                cf pilot_eq = out[p] / H[k];
+                cf pilot_eq = cdiv(out[p], H[k]);
                 /* mpsk_snr_est_simple::update: Welford mean/variance of |x| (double) */
                 double x = sqrtf(crealf(pilot_eq) * crealf(pilot_eq) + cimagf(pilot_eq) * cimagf(pilot_eq)); /* |x|, IEEE ops */
                 double y1_prime = y1 + (x - y1) / counter;
                 y2 += (x - y1) * (x - y1_prime);
                 y1 = y1_prime;
                 counter++;
-                H[k] = alpha * H[k] + (1 - alpha) * out[p] / pilot_sym[pset * N + k];
+                H[k] = alpha * H[k] + cdiv((1 - alpha) * out[p], pilot_sym[pset * N + k]);
                 out[p] = pilot_sym[pset * N + k];
             } else {
-                cf sym_eq = out[p] / H[k];
+                cf sym_eq = cdiv(out[p], H[k]);
                 cf sym_est = to_cf(pts[orc_decision_maker(cnst, from_cf(sym_eq))]);
-                H[k] = alpha * H[k] + (1 - alpha) * out[p] / sym_est;
+                H[k] = alpha * H[k] + cdiv((1 - alpha) * out[p], sym_est);
                 out[p] = sym_est;
                 if (soft) soft[p] = from_cf(sym_eq);
             }

@@ -95,7 +95,7 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
             if has_fec:
                 nb = ns * rf["hdr"]["cnst"]
                 got = llr[f["llr_offset"]:f["llr_offset"] + nb]
-                _close(got, ref["llr"][i][:nb], rtol=2e-5, atol=1e-4, what="llr frame %d" % i)
+                _close(got, ref["llr"][i][:nb], rtol=1e-5, what="llr frame %d" % i)  # north_star: 1e-5 relative
                 _count_exact("llr", got, ref["llr"][i][:nb])
         pi += 1
     assert pi == res.n_payload_frames
