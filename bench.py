@@ -7,9 +7,14 @@ Workload (config.workload): BASELINE.json configs[2] -- 256-subcarrier OFDM, 16-
 64k-frame batch on one GPU; with --gpus N every rank owns its own 64k-frame shard (configs[3]:
 512k frames over 8 GPUs) -> weak scaling, no data-path collective (frames are independent).
 
+`python bench.py --gpus N` starts the N ranks itself (torch.distributed.run on 127.0.0.1); under a launcher it reads
+RANK / LOCAL_RANK / WORLD_SIZE from the environment and --gpus must equal WORLD_SIZE.
+
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (LDPC BP) with SURVEY 8(d)'s
-algorithmic bytes per sample; `cpu_baseline` times the CPU oracle (a port of the reference chain, see
-oracle/) on a bounded sample of the same stream.
+algorithmic bytes per sample (and carries `saturated`: the same kernel at ~9 iterations per codeword);
+`cpu_baseline` times the CPU oracle (a port of the reference chain, see oracle/) on a bounded sample of the same
+stream; `extra` holds the same step in the production arithmetic, further operating points and, for N > 1, the
+root-fed scatter / decode / gather times.
 """
 import argparse
 import json
@@ -24,11 +29,15 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: fft_len, frame_length, constellation, Es/N0 dB, sync_threshold, frames, algorithmic B/sample
+    # Es/N0: the lowest (1 dB grid) at which the chain synchronises with the reference's default sync_threshold 0.95,
+    # i.e. >= 99 % of the frames are found and decoded (tools/op_point.py, profiles/r02/op_point_*.json)
     "c2": dict(fft_len=64, frame_length=20, cnst=2, esn0_db=12.0, sync_threshold=0.95, frames=4096, bytes_per_sample=8.06,
                desc="64-subcarrier OFDM, QPSK, LDPC n=300 k=152, 4k-frame batch"),
-    "c3": dict(fft_len=256, frame_length=20, cnst=4, esn0_db=23.0, sync_threshold=0.98, frames=65536, bytes_per_sample=8.13,
+    "c3": dict(fft_len=256, frame_length=20, cnst=4, esn0_db=18.0, sync_threshold=0.95, frames=65536, bytes_per_sample=8.13,
                desc="256-subcarrier OFDM, 16-QAM, LDPC(300,152), 64k-frame batch"),
 }
+# further Es/N0 points of a workload reported in `extra` (single-GPU runs): the decoder's load falls with Es/N0
+OTHER_POINTS = {"c3": (20.0, 23.0), "c2": (14.0,)}
 ES = {1: 1.0, 2: 0.25, 3: 1.0, 4: 1.0}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -133,6 +142,119 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def decoder_under_load(dtl, device, arith, ncw=1 << 20, esn0_db=-1.0, reps=3):
+    """ldpc_bp_np_kernel alone on codewords that need ~9 iterations each (BPSK over AWGN at Es/N0 = -1 dB, the
+    waterfall of the (300,152) code): codeword-iterations/s at saturation, timed with HIP events on the launch
+    stream.  -> dict"""
+    import torch
+    dec = dtl.ldpc_dec("n_0300_k_0152_gap_03.alist", arith=arith)
+    n, k = dec.get_n(), dec.get_k()
+    sig2 = 10 ** (-esn0_db / 10) / 2
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1)
+    y = -1.0 + torch.randn((ncw, n), device=device, generator=gen) * sig2 ** 0.5        # all-zero codeword
+    llr = (2 * y / sig2).float()
+    del y
+    bits = torch.empty((ncw, k), dtype=torch.uint8, device=device)
+    nit = torch.empty((ncw,), dtype=torch.int32, device=device)
+    dec.decode_batch(llr, bits, nit)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dec.decode_batch(llr, bits, nit)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    its = float(nit.float().mean().item())
+    # instruction bound: wave instructions of one iteration of the kernel's loop (ISA listing, profiles/r02/
+    # ldpc_isa_counts.txt) x 4 cycles, 1024 SIMDs at 2.4 GHz
+    instr = LDPC_WAVE_INSTR_PER_ITERATION[arith]
+    bound = 1024 * 2.4e9 / (instr * 4.0)
+    rate = ncw * its / (ms * 1e-3)
+    return {"arith": arith, "codewords": ncw, "iterations_per_codeword": round(its, 3), "kernel_ms": round(ms, 3),
+            "codeword_iterations_per_s": round(rate, 1), "wave_instructions_per_iteration": instr,
+            "instruction_bound_codeword_iterations_per_s": round(bound, 1), "instruction_bound_frac": round(rate / bound, 4),
+            "hbm_GBps": round(ncw * (n * 4 + k) / (ms * 1e-3) / 1e9, 1)}
+
+
+# wave instructions in one belief-propagation iteration of ldpc_bp_np_kernel<6,3,5,true,*> (tools/isa_loops.py on the
+# built code object; profiles/r02/ldpc_isa_counts.txt)
+LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 1159, "fast": 1159}
+
+
+def timed_steps(rx, x, steps, warmup, barrier):
+    """W untimed + exactly K timed passes of the receive path; -> (elapsed s, last result, mean decoder-kernel ms,
+    mean payload-kernel ms, summed host stage ms)"""
+    res = None
+    ldpc_ms, payload_ms, stage = [], [], np.zeros(8)
+    for _ in range(warmup):
+        res = rx.work(x, copy_outputs=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        # results stay where the C ABI leaves them (payload bytes in HBM, per-frame / per-block records in the
+        # handle's host memory); the numpy copies of the records are made on first read (after the timed region)
+        res = None
+        res = rx.work(x, copy_outputs=False)
+        ldpc_ms.append(res.stage_ms[6])
+        payload_ms.append(res.stage_ms[7])
+        stage += np.array(res.stage_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, res, float(np.mean(ldpc_ms)) if ldpc_ms else 0.0, float(np.mean(payload_ms)) if payload_ms else 0.0, stage
+
+
+def decode_stats(rx, x, res, n_user):
+    extra = rx.work(x, want=("cw",))                      # untimed: per-codeword iteration counts
+    nit = extra.cw_nit.float() if extra.cw_nit is not None else None
+    return {"frames_decoded": int(res.n_payload_frames), "tbs": int(len(res.tbs)),
+            "tbs_crc_ok": int((res.tbs["crc_ok"] == 1).sum()),
+            "avg_bp_iterations_per_tb": round(float(res.tbs["avg_it"].mean()) if len(res.tbs) else 0.0, 3),
+            "bp_iterations_per_codeword": round(float(nit.mean().item()) if nit is not None else 0.0, 3),
+            "codewords_zero_iterations": round(float((nit == 0).float().mean().item()) if nit is not None else 0.0, 4),
+            "codewords_at_max_iterations": round(float((nit == 15).float().mean().item()) if nit is not None else 0.0, 4),
+            "codewords": int(res.n_codewords), "payload_bytes": int(res.n_payload_bytes), "user_bytes_sent": int(n_user)}
+
+
+def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2):
+    """SURVEY 8(e) "report both": ONE rank holds the whole stream (world x the per-GPU batch), scatter over xGMI ->
+    decode -> gather; times of the three phases, max over ranks (tools/root_fed.py is the stand-alone form)."""
+    import torch
+    from gr_dtl_amd.sharding import combine, gather_results, owned_payload, scatter_stream
+    rank, world = dist.get_rank(), dist.get_world_size()
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    x = None
+    if rank == 0:
+        x, n_frames, _, _ = synth_stream(dtl, cfg, w, frames_per_gpu * world, device, seed=1000)
+        meta[0], meta[1] = n_frames, x.numel()
+    dist.broadcast(meta, 0)
+    n_frames, total = int(meta[0]), int(meta[1])
+    best = None
+    for _ in range(1 + steps):                                # first pass = warm-up (RCCL channel set-up)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        mine, plan = scatter_stream(x, n_frames, rx.frame_samples, 100, total, dist, device=device)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = rx.work(mine)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        data, tbs = owned_payload(res, plan, on_device=True)
+        got, recs = gather_results(data, tbs, dist, device=device)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        del mine
+        cur = (t1 - t0, t2 - t1, t3 - t2)
+        if best is None or sum(cur) < sum(best[:3]):
+            best = cur + (int(got.numel()) if got is not None else 0, int(len(recs)) if recs is not None else 0)
+    (ts, _), (td, _), (tg, _) = (combine(v, [0], dist, device) for v in best[:3])
+    return {"frames": n_frames, "samples": total, "scatter_ms": round(ts * 1e3, 3), "decode_ms": round(td * 1e3, 3),
+            "gather_ms": round(tg * 1e3, 3), "msamples_per_s_decode_only": round(total / td / 1e6, 1),
+            "msamples_per_s_with_exchange": round(total / (ts + td + tg) / 1e6, 1),
+            "payload_bytes": best[3], "blocks": best[4], "backend": "nccl (RCCL, point-to-point over xGMI)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,10 +262,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's batch)")
-    ap.add_argument("--in-flight", type=int, default=1, choices=(1, 2),
-                    help="receivers decoding alternate steps concurrently on their own HIP streams / host threads "
-                         "(2: the host phases and the sync kernel of one batch overlap the decoder kernels of the other)")
+    ap.add_argument("--esn0", type=float, default=None, help="override the workload's Es/N0 (dB)")
+    ap.add_argument("--arith", default="gr_exact", choices=("gr_exact", "fast"),
+                    help="arithmetic of the headline line (default: the reference's operations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fast arithmetic, other "
+                    "operating points, decoder under load, root-fed exchange)")
     ap.add_argument("--cpu-frames", type=int, default=0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (default: all, at most 16)")
     args = ap.parse_args()
@@ -170,15 +294,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switch for a box without one GPU per rank (the real multi-GPU run does not use it): every rank on
+    # device 0 with the gloo backend exercises the multi-process path; DTL_BENCH_REHEARSAL_GLOO=cpu stops before
+    # the first GPU call (launcher / rendezvous check on a machine without any GPU)
+    rehearsal = os.environ.get("DTL_BENCH_REHEARSAL_GLOO", "")
+    dist = None
+    if rehearsal == "cpu":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        print("bench.py: %d ranks joined (backend gloo, no GPU: launcher rehearsal only)" % dist.get_world_size(), file=sys.stderr)
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"rehearsal": "launcher", "n_gpus": dist.get_world_size(),
+                                             "rank_sum": float(t.item())}) + "\n").encode())
+        dist.destroy_process_group()
+        return 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    # rehearsal switches for a one-GPU box (the real multi-GPU run uses neither): every rank on device 0 with the
-    # gloo backend exercises the multi-process path; DTL_BENCH_FORCE_DIST initialises RCCL with a single rank
-    rehearsal = os.environ.get("DTL_BENCH_REHEARSAL_GLOO") == "1"
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    dist = None
     force_dist = os.environ.get("DTL_BENCH_FORCE_DIST") == "1"
     if world > 1 or (force_dist and "RANK" in os.environ):
         import torch.distributed as dist
@@ -187,10 +324,15 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+        if rank == 0:
+            print("bench.py: %d ranks joined (backend %s)" % (dist.get_world_size(), dist.get_backend()), file=sys.stderr)
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.esn0 is not None:
+        w["esn0_db"] = args.esn0
     n_frames_req = args.frames or w["frames"]
     cfg = build_config(dtl, w)
+    cfg.arith = args.arith
     rx = dtl.ofdm_receiver(cfg)
     x, n_frames, n_user, _ = synth_stream(dtl, cfg, w, n_frames_req, device, seed=rank)
     n_samples = x.numel()
@@ -202,70 +344,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    ldpc_ms, payload_ms, stage = [], [], np.zeros(8)
-    if args.in_flight == 1:
-        for _ in range(args.warmup):
-            res = rx.work(x, copy_outputs=False)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            # results stay where the C ABI leaves them (payload bytes in HBM, per-frame / per-block records in the
-            # handle's host memory); the numpy copies of the records are made on first read (after the timed region)
-            res = None
-            res = rx.work(x, copy_outputs=False)
-            ldpc_ms.append(res.stage_ms[6])
-            payload_ms.append(res.stage_ms[7])
-            stage += np.array(res.stage_ms)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    else:
-        import threading
-        rxs = [rx, dtl.ofdm_receiver(cfg)]
-        streams = [torch.cuda.Stream(device=device) for _ in rxs]
-        last = [None, None]
-        share = [args.steps - args.steps // 2, args.steps // 2]        # exactly K steps in total
-
-        def run(i, count):
-            torch.cuda.set_device(device)
-            with torch.cuda.stream(streams[i]):
-                for _ in range(count):
-                    r = last[i] = None
-                    r = rxs[i].work(x, copy_outputs=False)
-                    last[i] = r
-                    ldpc_ms.append(r.stage_ms[6])
-                    payload_ms.append(r.stage_ms[7])
-
-        def both(counts):
-            ths = [threading.Thread(target=run, args=(i, counts[i])) for i in range(2)]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-        both([max(1, args.warmup - args.warmup // 2), max(1, args.warmup // 2)])
-        barrier()
-        t0 = time.perf_counter()
-        both(share)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        res = last[0]
-        stage = np.array(res.stage_ms) * args.steps
     from gr_dtl_amd.sharding import combine
+    cdev = None if rehearsal else device
+    elapsed, res, t_ldpc, t_payload, stage = timed_steps(rx, x, args.steps, args.warmup, barrier)
     # max-over-ranks time, summed counters (two tiny all-reduces; no data-path collective)
-    elapsed, tot = combine(elapsed, [n_samples, res.n_payload_bytes, res.n_payload_frames, res.n_codewords],
-                           dist, None if rehearsal else device)
+    elapsed, tot = combine(elapsed, [n_samples, res.n_payload_bytes, res.n_payload_frames, res.n_codewords], dist, cdev)
     total_samples = float(tot[0])
     ms_per_step = elapsed / args.steps * 1e3
     value = total_samples * args.steps / elapsed / 1e6
 
+    extras = {}
+    other = "fast" if args.arith == "gr_exact" else "gr_exact"
+    if not args.no_extras:
+        # (1) the same step in the other arithmetic, on every rank (same input, same barriers, max over ranks)
+        cfg2 = build_config(dtl, w)
+        cfg2.arith = other
+        rx2 = dtl.ofdm_receiver(cfg2)
+        e2, res2, l2, p2, _ = timed_steps(rx2, x, args.steps, 1, barrier)
+        e2, tot2 = combine(e2, [n_samples], dist, cdev)
+        extras["other_arith"] = {"arith": other, "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                                 "value": round(float(tot2[0]) * args.steps / e2 / 1e6, 3), "unit": "Msamples/s",
+                                 "ldpc_kernel_ms": round(l2, 3), "payload_kernels_ms": round(p2, 3)}
+        if rank == 0:
+            extras["other_arith"]["stats_rank0"] = decode_stats(rx2, x, res2, n_user)
+        del rx2, res2
+
     out = None
     if rank == 0:
-        extra = rx.work(x, want=("cw",))                      # untimed: per-codeword iteration counts
-        cw_it = float(extra.cw_nit.float().mean().item()) if extra.cw_nit is not None else 0.0
-        cw_max = float((extra.cw_nit == 15).float().mean().item()) if extra.cw_nit is not None else 0.0
-        ok_tbs = int((res.tbs["crc_ok"] == 1).sum())
-        avg_it = float(res.tbs["avg_it"].mean()) if len(res.tbs) else 0.0
-        t_ldpc = float(np.mean(ldpc_ms)) if ldpc_ms else 0.0
+        st = decode_stats(rx, x, res, n_user)
         alg_bytes = w["bytes_per_sample"] * n_samples            # bytes/sample x samples per launch
         achieved = alg_bytes / (t_ldpc * 1e-3) / 1e9 if t_ldpc > 0 else 0.0
         traffic = None
@@ -275,6 +381,10 @@ def main():
                 traffic = json.load(open(tpath)).get("ldpc_bp_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        st.update({"ldpc_kernel_ms": round(t_ldpc, 3), "payload_kernels_ms": round(t_payload, 3),
+                   "host_stage_ms": [round(float(v) / args.steps, 3) for v in stage[:6]],
+                   "whole_chain_hbm_GBps": round(w["bytes_per_sample"] * value / 1e3, 2),
+                   "whole_chain_hbm_frac": round(w["bytes_per_sample"] * value / 1e3 / world / HBM_PEAK_GBPS, 5)})
         out = {
             "metric": "Msamples/s thru OFDM RX (sync>FFT>eq>demap>LDPC)", "value": round(value, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,26 +393,70 @@ def main():
             "config": {"workload": w["desc"], "fft_len": w["fft_len"], "frames_per_gpu": n_frames,
                        "samples_per_gpu": n_samples, "constellation": int(w["cnst"]), "esn0_db": w["esn0_db"],
                        "sync_threshold": w["sync_threshold"], "ldpc": "n=300 k=152, <=15 it, f64 LR-domain SPA",
-                       "parallelism": "frame-batch shard per GPU (dp%d), no data-path collective" % world,
-                       "batches_in_flight_per_gpu": args.in_flight},
+                       "arith": args.arith,
+                       "parallelism": "frame-batch shard per GPU (dp%d), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": "ldpc_bp_np_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "kernel_ms": round(t_ldpc, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "kernel is FP64-VALU/LDS bound (4 f64 divisions per Tanner edge per iteration), "
-                                 "not HBM bound; see DESIGN.md"},
-            "stats": {"frames_decoded": int(res.n_payload_frames), "tbs": int(len(res.tbs)), "tbs_crc_ok": ok_tbs,
-                      "avg_bp_iterations_per_tb": round(avg_it, 3), "bp_iterations_per_codeword": round(cw_it, 3),
-                      "codewords_at_max_iterations": round(cw_max, 4), "codewords": int(res.n_codewords),
-                      "payload_bytes": int(res.n_payload_bytes), "user_bytes_sent": int(n_user),
-                      "payload_kernel_ms": round(float(np.mean(payload_ms)), 3),
-                      "host_stage_ms": [round(float(s) / args.steps, 3) for s in stage[:6]],
-                      "whole_chain_hbm_GBps": round(w["bytes_per_sample"] * value / 1e3, 2)},
+                         "note": "achieved = SURVEY 8(d) whole-chain algorithmic bytes of the samples one launch serves / "
+                                 "the kernel's duration; the kernel's real limiter is the FP64 VALU (IEEE divisions), "
+                                 "see `saturated` for its instruction-bound fraction"},
+            "stats": st,
         }
-        if not args.no_cpu_baseline:
+    if not args.no_extras and not rehearsal:
+        if rank == 0 and world == 1:
+            # (2) the decoder kernel under load (~9 iterations per codeword), both arithmetics
+            sat = {a: decoder_under_load(dtl, device, a) for a in ("gr_exact", "fast")}
+            out["roofline"]["saturated"] = sat[args.arith]
+            extras["decoder_under_load"] = sat
+            # every codeword at the iteration limit: the step time with the decoder kernel replaced by that load
+            r = sat[args.arith]["codeword_iterations_per_s"]
+            out["stats"]["worst_case_ms_per_step"] = round(ms_per_step - t_ldpc + out["stats"]["codewords"] * 15 / r * 1e3, 3)
+            # (3) the same workload at other operating points (decoder load falls with Es/N0)
+            pts = []
+            for esn0 in OTHER_POINTS.get(args.workload, ()):
+                w3 = dict(w, esn0_db=esn0)
+                x3, nf3, nu3, _ = synth_stream(dtl, cfg, w3, n_frames_req, device, seed=rank)
+                e3, res3, l3, p3, _ = timed_steps(rx, x3, 3, 1, barrier)
+                rec = {"esn0_db": esn0, "arith": args.arith, "ms_per_step": round(e3 / 3 * 1e3, 3),
+                       "value": round(x3.numel() * 3 / e3 / 1e6, 3), "ldpc_kernel_ms": round(l3, 3)}
+                rec.update(decode_stats(rx, x3, res3, nu3))
+                pts.append(rec)
+                del x3, res3
+            extras["other_operating_points"] = pts
+        if world > 1:
+            # (4) root-fed operation (scatter / decode / gather).  A watchdog ends the run with the headline line if
+            # the exchange does not come back (it is the one part of this file no 1-GPU box can rehearse over RCCL).
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    extras["root_fed"] = {"error": "exchange did not finish within 240 s"}
+                    out["extra"] = extras
+                    os.write(result_fd, (json.dumps(out) + "\n").encode())
+                os._exit(0)
+            timer = threading.Timer(240.0, give_up)
+            timer.daemon = True
+            timer.start()
+            try:
+                del x
+                rf = root_fed_record(dtl, cfg, w, rx, n_frames_req, dist, device)
+                if rank == 0:
+                    extras["root_fed"] = rf
+            except Exception as e:  # the headline must survive a failure of the secondary record
+                if rank == 0:
+                    extras["root_fed"] = {"error": repr(e)[:300]}
+            timer.cancel()
+    if rank == 0:
+        if extras:
+            out["extra"] = extras
+        if not args.no_cpu_baseline and world == 1:
             cores = args.cpu_cores or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-            nfs = args.cpu_frames or min(n_frames, 1024 * cores)          # ~1.4 s of CPU work per 1024 C3 frames
+            nfs = args.cpu_frames or min(n_frames, 1024 * cores)          # ~5 s of CPU work per 1024 C3 frames at 18 dB
             nfs = min(nfs, n_frames)
+            if "x" not in locals() or x is None:
+                x, _, _, _ = synth_stream(dtl, cfg, w, nfs + 2, device, seed=rank)
             ns = 100 + nfs * rx.frame_samples + rx.frame_samples // 2
             out["cpu_baseline"] = cpu_baseline(cfg, w, x[:ns].cpu().numpy(), nfs, rx.frame_samples, cores)
         sys.stdout.flush()
@@ -310,7 +464,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    return out
+    return 0
 
 
 if __name__ == "__main__":

@@ -63,6 +63,7 @@ def lib():
     L.dtl_ldpc_create_from_text.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_float, C.POINTER(_vp)]
     L.dtl_ldpc_destroy.argtypes = [_vp]
     L.dtl_ldpc_destroy.restype = None
+    L.dtl_ldpc_set_arith.argtypes = [_vp, C.c_int32]
     L.dtl_ldpc_get_n.argtypes = [_vp]
     L.dtl_ldpc_get_k.argtypes = [_vp]
     L.dtl_ldpc_get_permute.argtypes = [_vp, _vp]

@@ -80,6 +80,13 @@ int dtl_ldpc_create(const char* path, int max_iterations, float sigma, dtl_ldpc*
 }
 
 void dtl_ldpc_destroy(dtl_ldpc* h) { delete h; }
+
+int dtl_ldpc_set_arith(dtl_ldpc* h, int32_t arith)
+{
+    if (!h || (arith != DTL_ARITH_GR_EXACT && arith != DTL_ARITH_FAST)) { dtl::set_last_error("ldpc_set_arith: bad argument"); return DTL_ERR_INVALID_ARG; }
+    h->dec.arith = arith;
+    return DTL_OK;
+}
 int dtl_ldpc_get_n(const dtl_ldpc* h) { return h ? h->dec.code.n : DTL_ERR_INVALID_ARG; }
 int dtl_ldpc_get_k(const dtl_ldpc* h) { return h ? h->dec.code.k : DTL_ERR_INVALID_ARG; }
 
@@ -163,6 +170,8 @@ static int fill_config(const dtl_rx_cfg* c, dtl::RxConfig& g, const char* who)
     for (int i = 0; i < c->n_fec_codes; i++) g.alist_texts.emplace_back(c->alist_texts[i], c->alist_lens[i]);
     for (int i = 0; i < c->n_mcs; i++) g.mcs.push_back({ c->mcs_snr[i], c->mcs_cnst[i], c->mcs_fec[i] });
     g.initial_mcs = c->initial_mcs; g.hysteresis = c->hysteresis; g.decision_th = c->decision_th > 0 ? c->decision_th : 5;
+    if (c->arith != DTL_ARITH_GR_EXACT && c->arith != DTL_ARITH_FAST) { dtl::set_last_error(std::string(who) + ": arith must be DTL_ARITH_GR_EXACT or DTL_ARITH_FAST"); return DTL_ERR_INVALID_ARG; }
+    g.arith = c->arith;
     return DTL_OK;
 }
 

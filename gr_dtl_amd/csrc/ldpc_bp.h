@@ -4,6 +4,8 @@
 #include "dtl_common.h"
 #include "ldpc_code.h"
 
+#include <atomic>
+
 namespace dtl {
 
 // Where one codeword's on-air soft bits live and where its decoded bits go
@@ -40,6 +42,7 @@ public:
     LdpcCode code;
     int max_iterations = 15;  // lib/dtl/ldpc_dec.cc:27
     float sigma = 1.41421356237f; // awgn_bp sigma: never set by gr-dtl; sqrt(2) => rx_lr = exp(llr)
+    int arith = 0;            // DTL_ARITH_GR_EXACT (awgn_bp's operations) / DTL_ARITH_FAST (see ldpc_bp.hip)
 
     ~LdpcDecoder();
     int upload();  // build device tables
@@ -60,7 +63,9 @@ private:
     bool np_rows_full_ = false;              // every row has exactly MAXR entries
     int np_maxr_ = 6;
     const uint16_t* np_perm_ = nullptr;
-    unsigned int* np_queue_ = nullptr;  // ticket counter of the codeword queue (one decode() in flight per decoder)
+    static constexpr unsigned kNpQueueRing = 256;
+    unsigned int* np_queue_ = nullptr;  // ring of ticket counters of the codeword queue: one per launch
+    mutable std::atomic<unsigned> np_launch_{ 0 };
     size_t np_lds_ = 0;
     bool np_ok_ = false;
 };

@@ -172,7 +172,34 @@ __device__ __forceinline__ void wave_sync()
 // product -- and a padded column entry names the message slot kept at 1.0 (factor 1 in the column product)
 // while its write is redirected to a trash slot.  Multiplying by exactly 1.0 changes no bit of a product, so
 // the arithmetic is still the reference's, without per-edge degree tests and without row/column pointer reads.
-template <int MAXR, int MAXC, int NV, bool ROWS_FULL>
+// FAST (dtl_ldpc_set_arith(h, DTL_ARITH_FAST); NOT the reference's bits -- oracle: orc_ldpc_decode_fast): the same
+// recursion with ONE division per batch of a row's quotients (prefix products, one reciprocal, walk back) and prefix x
+// suffix extrinsic products instead of (full product) / own factor: 2 divisions per check per iteration instead of
+// 4 per edge.  Channel LLR, check-node products and variable-to-check ratios are clamped so that every intermediate
+// stays finite (the reference's form saturates to 0 / inf and then NaN, whose decision is 0 whatever was sent).
+constexpr float kFastLlrMax = 40.0f;
+constexpr double kFastPMax = 1.0 - 0x1p-20;
+constexpr double kFastQMax = 0x1p+100, kFastQMin = 0x1p-100;
+
+// out[j] = num[j] / den[j], j < D, with one division: P_j = den_0 .. den_j, I = 1 / P_{D-1}, then
+// 1 / den_j = I P_{j-1}, I <- I den_j walking back (the operation order of the oracle's batch_quotients)
+template <int D>
+__device__ __forceinline__ void batch_quotients(const double (&num)[D], const double (&den)[D], double (&out)[D])
+{
+    double P[D];
+    P[0] = den[0];
+#pragma unroll
+    for (int j = 1; j < D; j++) P[j] = P[j - 1] * den[j];
+    double I = 1 / P[D - 1];
+#pragma unroll
+    for (int j = D - 1; j >= 1; j--) {
+        out[j] = num[j] * (I * P[j - 1]);
+        I = I * den[j];
+    }
+    out[0] = num[0] * I;
+}
+
+template <int MAXR, int MAXC, int NV, bool ROWS_FULL, bool FAST>
 __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables t, NpShared sh,
                                                                      const uint16_t* __restrict__ chk_var_g,
                                                                      const uint16_t* __restrict__ var_edge_g,
@@ -321,6 +348,47 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             }
         }
     };
+    // FAST: lane == check node in every pass (the two-lanes-per-check tail of the exact form shares a division
+    // sequence between lanes; here a row has only two divisions to begin with)
+    auto check_phase_fast = [&](auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        for (int c0 = 0; c0 < t.m; c0 += kWave) {
+            const int c = c0 + lane;
+            if (c < t.m) {
+                double* row = msg + c * MAXR;
+                const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
+                double a[MAXR], b[MAXR], tt[MAXR];
+#pragma unroll
+                for (int j = 0; j < MAXR; j++) {
+                    const double q = FIRST ? rx[chk_var[c * MAXR + j]] : row[j];
+                    a[j] = 1 + q;
+                    b[j] = 1 - q;
+                }
+                batch_quotients<MAXR>(b, a, tt);          // t_j = (1 - Q_j) / (1 + Q_j)
+                if (!ROWS_FULL) {
+#pragma unroll
+                    for (int j = 0; j < MAXR; j++) tt[j] = j < deg ? tt[j] : 1.0; // padding: exactly neutral
+                }
+                double pre[MAXR], suf[MAXR];
+                pre[0] = 1.0;
+#pragma unroll
+                for (int j = 1; j < MAXR; j++) pre[j] = pre[j - 1] * tt[j - 1];
+                suf[MAXR - 1] = 1.0;
+#pragma unroll
+                for (int j = MAXR - 2; j >= 0; j--) suf[j] = suf[j + 1] * tt[j + 1];
+#pragma unroll
+                for (int j = 0; j < MAXR; j++) {
+                    double p = pre[j] * suf[j];
+                    p = fmin(fmax(p, -kFastPMax), kFastPMax);
+                    a[j] = (ROWS_FULL || j < deg) ? 1 + p : 1.0;
+                    b[j] = 1 - p;
+                }
+                batch_quotients<MAXR>(b, a, tt);          // R_j = (1 - p_j) / (1 + p_j)
+#pragma unroll
+                for (int j = 0; j < MAXR; j++) row[j] = (ROWS_FULL || j < deg) ? tt[j] : 0.0;
+            }
+        }
+    };
     float cur[NV], nxt[NV];
     Meta mcur{ 0, 0 }, mnxt{ 0, 0 };
     int cw = advance();
@@ -350,7 +418,11 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         wave_sync();
         int nit = 0;
         if (!syndrome_ok()) {
-            for (int v = lane; v < t.n; v += kWave) rx[v] = exp(double((-1 * 2 * ybuf[v]) / s2));
+            for (int v = lane; v < t.n; v += kWave) {
+                float arg = (-1 * 2 * ybuf[v]) / s2;
+                if (FAST) arg = fminf(fmaxf(arg, -kFastLlrMax), kFastLlrMax);
+                rx[v] = exp(double(arg));
+            }
             if (lane == 0) rx[t.n] = 0.0;
             wave_sync();
             // spa_initialize (Q_e = channel LR of the edge's variable) is folded into the first check pass, which reads
@@ -359,14 +431,40 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             wave_sync();
             while (nit < max_it) {
                 nit += 1;
-                if (nit == 1) check_phase(std::true_type{});
-                else check_phase(std::false_type{});
+                if (FAST) {
+                    if (nit == 1) check_phase_fast(std::true_type{});
+                    else check_phase_fast(std::false_type{});
+                } else {
+                    if (nit == 1) check_phase(std::true_type{});
+                    else check_phase(std::false_type{});
+                }
                 wave_sync();
                 // ---- update_vars + decision: lane == variable node
                 for (int v = lane; v < t.n; v += kWave) {
                     const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
                     int ee[MAXC];
                     double rr[MAXC];
+                    if (FAST) {
+                        // Q_i = (rx R_0 .. R_{i-1}) (R_{i+1} .. R_{d-1}): prefix x suffix, no division
+                        double pre[MAXC + 1], suf[MAXC];
+                        pre[0] = rx[v];
+#pragma unroll
+                        for (int i = 0; i < MAXC; i++) {
+                            ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
+                            rr[i] = msg[ee[i]];
+                            pre[i + 1] = pre[i] * rr[i];
+                        }
+                        suf[MAXC - 1] = 1.0;
+#pragma unroll
+                        for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
+#pragma unroll
+                        for (int i = 0; i < MAXC; i++) {
+                            const double q = pre[i] * suf[i];
+                            msg[ee[i] == kOneSlot ? kTrashSlot : ee[i]] = fmin(fmax(q, kFastQMin), kFastQMax);
+                        }
+                        est[v] = (pre[MAXC] > 1) ? 1 : 0;
+                        continue;
+                    }
                     double sum = rx[v];
 #pragma unroll
                     for (int i = 0; i < MAXC; i++) {
@@ -430,8 +528,8 @@ int LdpcDecoder::upload()
     size_t o_ss = put(sys_src.data(), sys_src.size() * 2);
     std::vector<uint16_t> perm16 = to16(code.permute);
     size_t o_pm = put(perm16.data(), perm16.size() * 2);
-    const unsigned int zero = 0;
-    size_t o_q = put(&zero, sizeof(zero));
+    const std::vector<unsigned int> zeros(kNpQueueRing, 0u);
+    size_t o_q = put(zeros.data(), zeros.size() * sizeof(unsigned int));
     // fixed-stride tables of the node-parallel kernel (see the kernel's comment)
     const bool small_code = code.max_row_deg <= 6 && code.max_col_deg <= 3 && code.n <= 320; // kernel <6,3,5>
     const int maxr = small_code ? 6 : 8;
@@ -492,10 +590,14 @@ int LdpcDecoder::upload()
         np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && n_slots + 2 < 65535 &&
                  np_lds_ <= 160 * 1024;
         if (np_ok_) {
-            for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, true>),
-                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, false>),
-                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, true>),
-                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, false>) })
+            for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, true, false>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, false, false>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, true, false>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, false, false>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, true, true>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, false, true>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, true, true>),
+                               reinterpret_cast<const void*>(ldpc_bp_np_kernel<8, 4, 8, false, true>) })
                 DTL_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(np_lds_)));
         }
     }
@@ -515,18 +617,28 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
     }
     if (np_ok_) {
         const int grid = int(std::min<size_t>((ncw + kNpWaves - 1) / kNpWaves, 256));
-        auto kern = np_maxr_ == 6 ? (np_rows_full_ ? ldpc_bp_np_kernel<6, 3, 5, true> : ldpc_bp_np_kernel<6, 3, 5, false>)
-                                  : (np_rows_full_ ? ldpc_bp_np_kernel<8, 4, 8, true> : ldpc_bp_np_kernel<8, 4, 8, false>);
+        auto kern = np_maxr_ == 6 ? (np_rows_full_ ? ldpc_bp_np_kernel<6, 3, 5, true, false> : ldpc_bp_np_kernel<6, 3, 5, false, false>)
+                                  : (np_rows_full_ ? ldpc_bp_np_kernel<8, 4, 8, true, false> : ldpc_bp_np_kernel<8, 4, 8, false, false>);
+        if (arith == DTL_ARITH_FAST)
+            kern = np_maxr_ == 6 ? (np_rows_full_ ? ldpc_bp_np_kernel<6, 3, 5, true, true> : ldpc_bp_np_kernel<6, 3, 5, false, true>)
+                                 : (np_rows_full_ ? ldpc_bp_np_kernel<8, 4, 8, true, true> : ldpc_bp_np_kernel<8, 4, 8, false, true>);
         // every wave stops at its first out-of-range ticket: the counter ends below n_chunks + #waves.
         // Large batches take 16 codewords per ticket (keeps the same-address atomics off the critical
         // path); small ones shrink the ticket so that all 4096 waves get work and the tail stays short (at 25 k
         // codewords, C2, two per ticket measured 0.36 ms against 0.44 ms for one or four).
         const int chunk = int(std::max<size_t>(1, std::min<size_t>(kNpChunk, ncw / (size_t(grid) * kNpWaves * 3))));
-        DTL_HIP_CHECK(hipMemsetAsync(np_queue_, 0, sizeof(unsigned int), stream));
+        // every launch takes its own ticket counter from a ring: two decodes of one decoder on different streams
+        // (legal: decode() is const and takes the caller's stream) never share one
+        unsigned int* queue = np_queue_ + (np_launch_.fetch_add(1, std::memory_order_relaxed) % kNpQueueRing);
+        DTL_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned int), stream));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_chk_var_, np_var_edge_, np_chk_deg_, np_perm_,
-                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, np_queue_, chunk);
+                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
+    }
+    if (arith == DTL_ARITH_FAST) {
+        set_last_error("ldpc: the fast arithmetic is implemented by the node-parallel kernel only (row weight <= 8, column weight <= 4, n <= 512)");
+        return DTL_ERR_UNSUPPORTED;
     }
     const size_t lds = lds_bytes();
     const int waves_per_cu = int(std::min<size_t>(16, (160 * 1024) / lds));

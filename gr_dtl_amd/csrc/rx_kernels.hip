@@ -669,11 +669,32 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 // relative to a rounding boundary, the f64 quotient is within 2^-53) and every quotient takes the refinement
 // half of the IEEE division sequence (dm_neg_div_by: 1 multiply + 4 FMAs instead of ~11 instructions);
 // quotients in the subnormal range all map to exp() == 1.  tools/math_check.hip checks both claims.
-template <int BPS, bool PLAIN_DIST>
+// MODE 0: squared distance / npwr (default), 1: plain distance / npwr, 2: FAST arithmetic (DTL_DEMAP_FAST; squared
+// distances): 16-QAM in the separable form -- exp(-(dx^2 + dy^2)/npwr) factors, the other axis' factor cancels in
+// P(bit = 1) / P(bit = 0), so a bit needs the 4 levels of its own axis: 8 exp + 8 log instead of 16 + 8 (oracle:
+// calc_soft_dec_qam16_fast; NOT the reference's bits).  Other constellations: as mode 0.
+template <int BPS, int MODE>
 __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, float npwr, float rinv,
                                                   float* __restrict__ o)
 {
     constexpr int M = 1 << BPS;
+    constexpr bool PLAIN_DIST = MODE == 1;
+    if constexpr (BPS == 4 && MODE == 2) {
+        float er[4], ei[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float dr = s.re - pts[q << 1].re;                        // points 0, 2, 4, 6: the four real levels
+            const float di = s.im - pts[(q & 1) | ((q >> 1) << 3)].im;     // points 0, 1, 8, 9: the four imaginary levels
+            er[q] = dm_exp(dm_neg_div_by(dr * dr, npwr, rinv));
+            ei[q] = dm_exp(dm_neg_div_by(di * di, npwr, rinv));
+        }
+        // index bit 1 / 2 = LSB / MSB of the real level, bit 0 / 3 = LSB / MSB of the imaginary level; LSB first
+        o[0] = dm_log(ei[1] + ei[3]) - dm_log(ei[0] + ei[2]);
+        o[1] = dm_log(er[1] + er[3]) - dm_log(er[0] + er[2]);
+        o[2] = dm_log(er[2] + er[3]) - dm_log(er[0] + er[1]);
+        o[3] = dm_log(ei[2] + ei[3]) - dm_log(ei[0] + ei[1]);
+        return;
+    }
     float p0[BPS], p1[BPS];
     cf32 lp[M];
 #pragma unroll
@@ -712,6 +733,13 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
     }
 #pragma unroll
     for (int j = 0; j < BPS; j++) o[j] = dm_log(p1[j]) - dm_log(p0[j]);
+}
+
+// dist_mode argument (0 / 1, + DTL_DEMAP_FAST) -> MODE of soft_demap_symbol; the fast form exists for squared distances
+static inline int demap_mode(int dist_mode)
+{
+    const int base = (dist_mode & 0xff) ? 1 : 0;
+    return ((dist_mode & 0x100) && base == 0) ? 2 : base;
 }
 
 struct Welford {
@@ -966,7 +994,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
 }
 
 // ofdm_adaptive_constellation_soft_cf over all frames of a batch: thread == data symbol (blockIdx.x == frame)
-template <bool PLAIN_DIST>
+template <int MODE>
 __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc* __restrict__ frames,
                                                    const FrameStat* __restrict__ stats,
                                                    const cf32* __restrict__ soft_syms,
@@ -984,10 +1012,10 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     const cf32 s = soft_syms[size_t(f) * t.frame_capacity + q];
     float* o = llr_out + size_t(llr_off[f]) + size_t(q) * bps;
     switch (bps) {
-    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
-    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
-    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
-    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts, npwr, rinv, o); break;
+    case 1: soft_demap_symbol<1, MODE>(s, pts, npwr, rinv, o); break;
+    case 2: soft_demap_symbol<2, MODE>(s, pts, npwr, rinv, o); break;
+    case 3: soft_demap_symbol<3, MODE>(s, pts, npwr, rinv, o); break;
+    default: soft_demap_symbol<4, MODE>(s, pts, npwr, rinv, o); break;
     }
 }
 
@@ -1145,7 +1173,7 @@ struct CnstPoints {
 };
 
 // ofdm_adaptive_constellation_soft_cf (soft_cf_impl.cc:89-148): bps soft bits per symbol, LSB first
-template <bool PLAIN_DIST>
+template <int MODE>
 __global__ __launch_bounds__(256) void soft_demap_kernel(const cf32* __restrict__ syms, int64_t n, int bps, CnstPoints pts,
                                                         float npwr, float rinv, float* __restrict__ llr)
 {
@@ -1154,10 +1182,10 @@ __global__ __launch_bounds__(256) void soft_demap_kernel(const cf32* __restrict_
     float* o = llr + i * bps;
     const cf32 s = syms[i];
     switch (bps) {
-    case 1: soft_demap_symbol<1, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
-    case 2: soft_demap_symbol<2, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
-    case 3: soft_demap_symbol<3, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
-    default: soft_demap_symbol<4, PLAIN_DIST>(s, pts.p, npwr, rinv, o); break;
+    case 1: soft_demap_symbol<1, MODE>(s, pts.p, npwr, rinv, o); break;
+    case 2: soft_demap_symbol<2, MODE>(s, pts.p, npwr, rinv, o); break;
+    case 3: soft_demap_symbol<3, MODE>(s, pts.p, npwr, rinv, o); break;
+    default: soft_demap_symbol<4, MODE>(s, pts.p, npwr, rinv, o); break;
     }
 }
 
@@ -1419,8 +1447,10 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
                            stats, eq_hard, eq_soft, soft_syms);
     if (t.has_fec) {
         const dim3 grid(n_frames, (t.frame_capacity + 255) / 256);
-        if (t.llr_dist_mode) hipLaunchKernelGGL(demap_kernel<true>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
-        else hipLaunchKernelGGL(demap_kernel<false>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
+        const int mode = demap_mode(t.llr_dist_mode);
+        if (mode == 1) hipLaunchKernelGGL(demap_kernel<1>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
+        else if (mode == 2) hipLaunchKernelGGL(demap_kernel<2>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
+        else hipLaunchKernelGGL(demap_kernel<0>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
     } else {
         hipLaunchKernelGGL(nofec_tail_kernel, dim3(n_frames), dim3(256), 0, st, t, frames, soft_syms, nofec_bytes, nofec_info,
                            nofec_stride);
@@ -1529,8 +1559,10 @@ int launch_soft_demap(const cf32* syms, int64_t n, int cnst, double noise, int d
     if (noise >= 0) sigma = std::sqrt(noise);
     const float npwr = float(sigma), rinv = float(1.0 / double(npwr));
     const int64_t grid = (n + 255) / 256;
-    if (dist_mode) hipLaunchKernelGGL(soft_demap_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, npwr, rinv, llr);
-    else hipLaunchKernelGGL(soft_demap_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, npwr, rinv, llr);
+    const int mode = demap_mode(dist_mode);
+    if (mode == 1) hipLaunchKernelGGL(soft_demap_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, npwr, rinv, llr);
+    else if (mode == 2) hipLaunchKernelGGL(soft_demap_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, npwr, rinv, llr);
+    else hipLaunchKernelGGL(soft_demap_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, syms, n, cnst, pts, npwr, rinv, llr);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

@@ -422,6 +422,7 @@ int Receiver::init()
         dec->code.build_schedules();
         dec->max_iterations = cfg.max_iterations > 0 ? cfg.max_iterations : 15;
         if (cfg.bp_sigma > 0) dec->sigma = cfg.bp_sigma;
+        dec->arith = cfg.arith;
         decoders_.push_back(std::move(dec));
     }
     if (cfg.has_fec && decoders_.size() < 2) { set_last_error("Misconfiguration: decoder not found!"); return DTL_ERR_INVALID_ARG; }
@@ -563,7 +564,7 @@ int Receiver::upload_tables()
     tab_.hdr_bits = 0;
     for (int i = 0; i < h; i++) tab_.hdr_bits += occ_len[i % n_occ_sets];
     tab_.g_min = gmin; tab_.g_max = gmax;
-    tab_.eq_alpha = cfg.eq_alpha; tab_.llr_dist_mode = cfg.llr_dist_mode;
+    tab_.eq_alpha = cfg.eq_alpha; tab_.llr_dist_mode = (cfg.llr_dist_mode & 0x1ff) | (cfg.arith == DTL_ARITH_FAST ? DTL_DEMAP_FAST : 0);
     tab_.twiddle = reinterpret_cast<const cf32*>(b + o_tw);
     tab_.bitrev = reinterpret_cast<const uint16_t*>(b + o_br);
     tab_.occ_idx = reinterpret_cast<const int16_t*>(b + o_oi);

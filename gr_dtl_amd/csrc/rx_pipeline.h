@@ -34,6 +34,7 @@ struct RxConfig {
     int llr_dist_mode = 0;
     int max_iterations = 15;
     float bp_sigma = 0.0f; // 0 => sqrt(2)
+    int arith = 0;         // DTL_ARITH_GR_EXACT / DTL_ARITH_FAST: decoder + 16-QAM demapper arithmetic
     std::vector<std::string> alist_texts; // fec_codes, index i -> FEC id i+1
     std::vector<McsEntry> mcs;
     int initial_mcs = 0;

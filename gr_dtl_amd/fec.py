@@ -27,11 +27,12 @@ def _resolve(path):
 class ldpc_dec:
     """gr::dtl::ldpc_dec (lib/dtl/ldpc_dec.h:19-38): alist file + max iterations (15)."""
 
-    def __init__(self, alist_fname, max_it=15, sigma=0.0):
+    def __init__(self, alist_fname, max_it=15, sigma=0.0, arith="gr_exact"):
         self._h = C.c_void_p()
         L = _lib.lib()
         _lib.check(L.dtl_ldpc_create(os.fsencode(_resolve(alist_fname)), int(max_it), float(sigma),
                                      C.byref(self._h)))
+        self.set_arith(arith)
         self._n = L.dtl_ldpc_get_n(self._h)
         self._k = L.dtl_ldpc_get_k(self._h)
 
@@ -41,6 +42,10 @@ class ldpc_dec:
                 _lib.lib().dtl_ldpc_destroy(self._h)
         except Exception:
             pass
+
+    def set_arith(self, arith):
+        """"gr_exact" (0): awgn_bp's operations, the reference's bits; "fast" (1): production arithmetic."""
+        _lib.check(_lib.lib().dtl_ldpc_set_arith(self._h, {"gr_exact": 0, "fast": 1}.get(arith, arith)))
 
     def get_k(self):
         return self._k
@@ -115,6 +120,6 @@ def make_ldpc_encoders(alist_fnames):
     return [None] + [ldpc_enc(f) for f in alist_fnames]
 
 
-def make_ldpc_decoders(alist_fnames, max_it=15):
+def make_ldpc_decoders(alist_fnames, max_it=15, arith="gr_exact"):
     """lib/dtl/ldpc_dec.cc:23-31: index 0 is None ("no FEC")."""
-    return [None] + [ldpc_dec(f, max_it) for f in alist_fnames]
+    return [None] + [ldpc_dec(f, max_it, arith=arith) for f in alist_fnames]

@@ -121,6 +121,8 @@ class ofdm_adaptive_rx_config(ofdm_adaptive_config):
     llr_dist_mode: int = 0      # constellation::calc_soft_dec distance: 0 squared, 1 plain
     ldpc_sigma: float = 0.0     # awgn_bp sigma (never set by gr-dtl); 0 -> sqrt(2)
     ldpc_max_iterations: int = 15
+    arith: str = "gr_exact"     # "gr_exact": the reference's operations (its bits); "fast": production arithmetic
+                                # of the BP decoder and the 16-QAM demapper (include/dtl_rx.h, enum dtl_arith)
 
 
 @dc.dataclass

@@ -58,9 +58,15 @@ def fft_batch(x, forward=True):
     return out
 
 
-def soft_demap(syms, constellation, noise=None, dist_mode=0):
-    """syms: complex64 device tensor (1-D) -> float32 soft bits, bits/symbol per symbol, LSB first."""
+DEMAP_FAST = 0x100   # DTL_DEMAP_FAST
+
+
+def soft_demap(syms, constellation, noise=None, dist_mode=0, arith="gr_exact"):
+    """syms: complex64 device tensor (1-D) -> float32 soft bits, bits/symbol per symbol, LSB first.
+    arith "fast": the separable 16-QAM form (DTL_DEMAP_FAST)."""
     import torch
+    if arith in ("fast", 1):
+        dist_mode = int(dist_mode) | DEMAP_FAST
     _need_device(syms, "soft_demap")
     L = _lib.lib()
     _declare(L)

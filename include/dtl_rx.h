@@ -34,6 +34,18 @@ enum dtl_constellation {
     DTL_CNST_UNKNOWN = 0, DTL_CNST_BPSK = 1, DTL_CNST_QPSK = 2, DTL_CNST_PSK8 = 3, DTL_CNST_QAM16 = 4
 };
 
+/* Arithmetic of the belief-propagation decoder and of the 16-QAM soft demapper.
+ * GR_EXACT (default): the reference's operations in the reference's order (GR awgn_bp: 4 double divisions per Tanner
+ *   edge per iteration; calc_soft_dec: one expf per constellation point) -- hard decisions and iteration counts equal
+ *   the reference decoder's.
+ * FAST: production arithmetic, algebraically the same sum-product / exact-MAP rules with fewer operations (one division
+ *   per batch of a row's quotients, prefix x suffix extrinsic products, bounded messages; separable 16-QAM
+ *   likelihoods: 8 expf instead of 16).  Results are bit-identical to the oracle's restatement of THIS arithmetic
+ *   (orc_ldpc_decode_fast, ORC_DEMAP_FAST), not to the reference's; BER is no worse. */
+enum dtl_arith { DTL_ARITH_GR_EXACT = 0, DTL_ARITH_FAST = 1 };
+/* flag added to a dist_mode argument / dtl_rx_cfg.llr_dist_mode: soft demapper in FAST arithmetic */
+#define DTL_DEMAP_FAST 0x100
+
 const char* dtl_last_error(void);
 const char* dtl_version(void);
 /* number of visible HIP devices (0 when none / runtime unusable) */
@@ -54,6 +66,8 @@ int dtl_ldpc_create(const char* alist_path, int max_iterations, float sigma, dtl
 int dtl_ldpc_create_from_text(const char* alist_text, size_t text_len, int max_iterations,
                               float sigma, dtl_ldpc** out);
 void dtl_ldpc_destroy(dtl_ldpc* h);
+/* enum dtl_arith; takes effect from the next decode call */
+int dtl_ldpc_set_arith(dtl_ldpc* h, int32_t arith);
 int dtl_ldpc_get_n(const dtl_ldpc* h);        /* fec_dec::get_n */
 int dtl_ldpc_get_k(const dtl_ldpc* h);        /* fec_dec::get_k */
 int dtl_ldpc_get_permute(const dtl_ldpc* h, int32_t* out_n); /* cldpc permutation (print_permute hack) */
@@ -118,6 +132,8 @@ typedef struct dtl_rx_cfg {
     int32_t initial_mcs;
     int32_t decision_th;             /* 5 (ofdm_receiver.py:167) */
     double hysteresis;               /* 1 */
+    int32_t arith;                   /* enum dtl_arith: decoder + 16-QAM demapper arithmetic (0 = the reference's) */
+    int32_t reserved0;
 } dtl_rx_cfg;
 
 /* header fields = the "header_data" dict of packet_headerparser_b; snr/noise/feedback = what
@@ -170,7 +186,9 @@ typedef struct dtl_rx_result {
     int32_t frame_capacity, hdr_bits, frame_samples, pad;
 } dtl_rx_result;
 
-/* Threading: one handle serves one call at a time (it owns its device buffers, staging memory and stream
+/* Threading: a dtl_ldpc handle may decode from several host threads / HIP streams at once (every launch has its own
+ * work-queue counter; dtl_ldpc_set_arith must not run concurrently with a decode).
+ * dtl_rx / dtl_tx: one handle serves one call at a time (it owns its device buffers, staging memory and stream
  * state); different handles may run concurrently from different host threads on different HIP streams
  * (bench.py --in-flight 2 does that to overlap one batch's host phases with another's decoder kernels). */
 int dtl_rx_create(const dtl_rx_cfg* cfg, dtl_rx** out);

@@ -62,7 +62,10 @@ int orc_constellation_points(int cnst, orc_c32* pts /* >=16 */);
 unsigned orc_decision_maker(int cnst, orc_c32 sample);
 /* GR3.10 constellation::calc_soft_dec (used at
  * lib/dtl/ofdm_adaptive_constellation_soft_cf_impl.cc:144); out[0..bps) MSB first.
- * dist_mode 0: |x-s|^2 / npwr (SURVEY 8c choice), 1: |x-s| / npwr. */
+ * dist_mode 0: |x-s|^2 / npwr (SURVEY 8c choice), 1: |x-s| / npwr.
+ * ORC_DEMAP_FAST added to dist_mode selects the production arithmetic (16-QAM with squared distances only:
+ * the 4 x 4 grid separates, P(bit) needs the 4 levels of ONE axis -- 8 exp instead of 16; other cases unchanged). */
+#define ORC_DEMAP_FAST 0x100
 void orc_calc_soft_dec(int cnst, orc_c32 sample, float npwr, int dist_mode, float* out);
 /* lib/dtl/ofdm_adaptive_constellation_soft_cf_impl.cc:143-148 (+ sigma rule :89-103):
  * n_syms symbols -> n_syms*bps LLRs, LSB first per symbol.  noise<0 => no noise tag. */
@@ -91,6 +94,15 @@ void orc_ldpc_encode(const orc_ldpc* c, const uint8_t* data_k, uint8_t* out_n);
  * makes rx_lr = exp(llr)).  Returns k. */
 int orc_ldpc_decode(const orc_ldpc* c, const float* llr_n, int max_it, float sigma,
                     uint8_t* out_k, int* nit);
+/* The decoder in PRODUCTION ("fast") arithmetic: the same sum-product recursion with one division per batch of
+ * quotients and prefix x suffix extrinsic products (orc_ldpc.c); NOT the reference's bits -- the oracle of the
+ * product's `arith = DTL_ARITH_FAST` mode.  arith: 0 = gr_exact (awgn_bp's operations), 1 = fast. */
+int orc_ldpc_decode_fast(const orc_ldpc* c, const float* llr_n, int max_it, float sigma,
+                         uint8_t* out_k, int* nit);
+int orc_ldpc_decode_arith(const orc_ldpc* c, const float* llr_n, int max_it, float sigma, int arith,
+                          uint8_t* out_k, int* nit);
+void orc_ldpc_decode_batch_arith(const orc_ldpc* c, const float* llr, int ncw, int max_it,
+                                 float sigma, int arith, uint8_t* out_bits, int* nit, int n_threads);
 /* batch helper (same function, ncw codewords back to back); n_threads>1 uses pthreads */
 void orc_ldpc_decode_batch(const orc_ldpc* c, const float* llr, int ncw, int max_it,
                            float sigma, uint8_t* out_bits, int* nit, int n_threads);
@@ -165,6 +177,7 @@ typedef struct {
 orc_tbdec* orc_tbdec_new(const orc_ldpc* c, int frame_capacity, int max_bps, int max_it,
                          float bp_sigma);
 void orc_tbdec_free(orc_tbdec* d);
+void orc_tbdec_set_arith(orc_tbdec* d, int arith);
 /* one frame through ofdm_adaptive_fec_decoder_impl::general_work (:80-217) ->
  * tb_decoder::process_frame (tb_decoder.cc:32-141) -> decode (:143-195) -> on_data_ready.
  * llr: len floats (len = n_syms*bps).  Appends user bits (1/byte) to out (cap out_cap) and TB
@@ -198,6 +211,7 @@ typedef struct {
     float bp_sigma;
     int max_it;
     int use_sync_correct;
+    int arith;                     /* 0: gr_exact (the reference's operations), 1: fast (BP + 16-QAM demapper) */
 } orc_cfg;
 
 /* python/dtl/ofdm_adaptive.py:1-6 */

@@ -74,6 +74,10 @@ def _declare(L):
     L.orc_ldpc_decode.restype = C.c_int
     L.orc_ldpc_decode.argtypes = [_P, _P, C.c_int, C.c_float, _P, _P]
     L.orc_ldpc_decode_batch.argtypes = [_P, _P, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int]
+    L.orc_ldpc_decode_arith.restype = C.c_int
+    L.orc_ldpc_decode_arith.argtypes = [_P, _P, C.c_int, C.c_float, C.c_int, _P, _P]
+    L.orc_ldpc_decode_batch_arith.argtypes = [_P, _P, C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, C.c_int]
+    L.orc_tbdec_set_arith.argtypes = [_P, C.c_int]
 
 
 # ---------------------------------------------------------------- bits / crc
@@ -139,7 +143,13 @@ def decision_maker(cnst, samples):
                     dtype=np.uint8)
 
 
-def soft_demap(cnst, syms, noise=None, dist_mode=0):
+GR_EXACT, FAST = 0, 1           # arithmetic modes (oracle.h: orc_cfg.arith); DEMAP_FAST is the flag on dist_mode
+DEMAP_FAST = 0x100
+
+
+def soft_demap(cnst, syms, noise=None, dist_mode=0, arith=GR_EXACT):
+    if arith:
+        dist_mode = int(dist_mode) | DEMAP_FAST
     syms = np.ascontiguousarray(syms, dtype=c32)
     bps = bits_per_symbol(cnst)
     out = np.zeros(syms.size * bps, dtype=np.float32)
@@ -181,22 +191,23 @@ class Ldpc:
         lib().orc_ldpc_encode(self._h, _ptr(data), _ptr(out))
         return out
 
-    def decode(self, llr, max_it=15, sigma=np.sqrt(2.0)):
+    def decode(self, llr, max_it=15, sigma=np.sqrt(2.0), arith=GR_EXACT):
         llr = np.ascontiguousarray(llr, dtype=np.float32)
         assert llr.size == self.n
         out = np.zeros(self.k, dtype=np.uint8)
         nit = C.c_int(0)
-        lib().orc_ldpc_decode(self._h, _ptr(llr), max_it, float(np.float32(sigma)), _ptr(out),
-                              C.byref(nit))
+        with np.errstate(all="ignore"):
+            lib().orc_ldpc_decode_arith(self._h, _ptr(llr), max_it, float(np.float32(sigma)), int(arith), _ptr(out),
+                                        C.byref(nit))
         return out, nit.value
 
-    def decode_batch(self, llr, max_it=15, sigma=np.sqrt(2.0), n_threads=1):
+    def decode_batch(self, llr, max_it=15, sigma=np.sqrt(2.0), n_threads=1, arith=GR_EXACT):
         llr = np.ascontiguousarray(llr, dtype=np.float32).reshape(-1, self.n)
         ncw = llr.shape[0]
         out = np.zeros((ncw, self.k), dtype=np.uint8)
         nit = np.zeros(ncw, dtype=np.int32)
-        lib().orc_ldpc_decode_batch(self._h, _ptr(llr), ncw, max_it, float(np.float32(sigma)),
-                                    _ptr(out), _ptr(nit), n_threads)
+        lib().orc_ldpc_decode_batch_arith(self._h, _ptr(llr), ncw, max_it, float(np.float32(sigma)), int(arith),
+                                          _ptr(out), _ptr(nit), n_threads)
         return out, nit
 
 
@@ -228,7 +239,7 @@ class Cfg(C.Structure):
                 ("n_pilots", C.c_int), ("pilot_carriers", _P), ("n_pilot_sym_sets", C.c_int),
                 ("pilot_symbols", _P), ("sync1", _P), ("sync2", _P), ("sync_threshold", C.c_float),
                 ("eq_alpha", C.c_float), ("scramble_header", C.c_int), ("llr_dist_mode", C.c_int),
-                ("bp_sigma", C.c_float), ("max_it", C.c_int), ("use_sync_correct", C.c_int)]
+                ("bp_sigma", C.c_float), ("max_it", C.c_int), ("use_sync_correct", C.c_int), ("arith", C.c_int)]
 
 
 class Snr(C.Structure):
@@ -343,7 +354,7 @@ class Config:
     def __init__(self, fft_len=64, cp_len=None, frame_length=20, has_fec=True, sync_threshold=0.95,
                  eq_alpha=0.1, llr_dist_mode=0, bp_sigma=float(np.sqrt(np.float32(2.0))), max_it=15,
                  use_sync_correct=True, occupied_carriers=None, pilot_carriers=None, pilot_symbols=None,
-                 sync_word1=None, sync_word2=None, scramble_header=False):
+                 sync_word1=None, sync_word2=None, scramble_header=False, arith=GR_EXACT):
         self.fft_len = fft_len
         self.cp_len = fft_len // 4 if cp_len is None else cp_len
         self.frame_length = frame_length
@@ -360,6 +371,7 @@ class Config:
         self.sync_threshold, self.eq_alpha = sync_threshold, eq_alpha
         self.llr_dist_mode, self.bp_sigma, self.max_it = llr_dist_mode, bp_sigma, max_it
         self.use_sync_correct, self.scramble_header = use_sync_correct, scramble_header
+        self.arith = int(arith)
         self._build()
 
     def _build(self):
@@ -384,6 +396,7 @@ class Config:
         c.sync_threshold, c.eq_alpha = self.sync_threshold, self.eq_alpha
         c.scramble_header, c.llr_dist_mode = int(self.scramble_header), int(self.llr_dist_mode)
         c.bp_sigma, c.max_it, c.use_sync_correct = self.bp_sigma, self.max_it, int(self.use_sync_correct)
+        c.arith = int(self.arith)
         self.c = c
 
     @property
@@ -542,11 +555,13 @@ def serialize(cfg, frame, symbols_skipped, packet_len):
 
 
 class TbDecoder:
-    def __init__(self, code, frame_capacity, max_bps=4, max_it=15, bp_sigma=float(np.sqrt(np.float32(2.0)))):
+    def __init__(self, code, frame_capacity, max_bps=4, max_it=15, bp_sigma=float(np.sqrt(np.float32(2.0))),
+                 arith=GR_EXACT):
         L = lib()
         L.orc_tbdec_new.restype = _P
         self._h = C.c_void_p(L.orc_tbdec_new(C.c_void_p(code._h), frame_capacity, max_bps, max_it,
                                               C.c_float(bp_sigma)))
+        L.orc_tbdec_set_arith(self._h, int(arith))
         self.code = code
 
     def __del__(self):

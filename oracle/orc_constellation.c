@@ -93,8 +93,39 @@ unsigned orc_decision_maker(int cnst, orc_c32 s)
 /* GR3.10 constellation::calc_soft_dec(sample, npwr): for every point d = expf(-dist/npwr),
  * accumulated per bit into P(0)/P(1); LLR_j = logf(P1) - logf(P0); returned MSB first.
  * (d_scalefactor = 1 for the built-in constellations.) */
+/* PRODUCTION ("fast") arithmetic for 16-QAM with squared distances (NOT the reference's bits): the GR 16-QAM
+ * table is a 4 x 4 grid -- index bits 1, 2 select the real level, bits 0, 3 the imaginary level
+ * (orc_decision_maker) -- and exp(-(dx^2 + dy^2)/npwr) = exp(-dx^2/npwr) exp(-dy^2/npwr), so the sums over the 8
+ * points with bit j set / clear share the other axis' factor, which cancels in the ratio: P(bit) needs only the 4
+ * levels of the bit's own axis.  8 exp + 8 log per symbol instead of 16 + 8.  Levels are visited in the order of the
+ * points' indices (real: points 0, 2, 4, 6; imaginary: points 0, 1, 8, 9).  out: MSB first. */
+static void calc_soft_dec_qam16_fast(orc_c32 sample, float npwr, float* out)
+{
+    orc_c32 pts[16];
+    orc_constellation_points(ORC_CNST_QAM16, pts);
+    float er[4], ei[4];
+    for (int q = 0; q < 4; q++) {
+        float dr = sample.re - pts[q << 1].re;                       /* real level of index bits (2,1) = q     */
+        float di = sample.im - pts[(q & 1) | ((q >> 1) << 3)].im;    /* imaginary level of index bits (3,0) = q */
+        er[q] = orc_expf(-(dr * dr) / npwr);
+        ei[q] = orc_expf(-(di * di) / npwr);
+    }
+    /* bit 1 = LSB of the real level index, bit 2 = its MSB; bit 0 = LSB of the imaginary level index, bit 3 = MSB */
+    float s[4][2];
+    s[1][0] = er[0] + er[2]; s[1][1] = er[1] + er[3];
+    s[2][0] = er[0] + er[1]; s[2][1] = er[2] + er[3];
+    s[0][0] = ei[0] + ei[2]; s[0][1] = ei[1] + ei[3];
+    s[3][0] = ei[0] + ei[1]; s[3][1] = ei[2] + ei[3];
+    for (int i = 0; i < 4; i++) out[3 - i] = orc_logf(s[i][1]) - orc_logf(s[i][0]);
+}
+
 void orc_calc_soft_dec(int cnst, orc_c32 sample, float npwr, int dist_mode, float* out)
 {
+    if ((dist_mode & ORC_DEMAP_FAST) && cnst == ORC_CNST_QAM16 && (dist_mode & 0xff) == 0) {
+        calc_soft_dec_qam16_fast(sample, npwr, out);
+        return;
+    }
+    dist_mode &= 0xff;
     orc_c32 pts[16];
     int M = orc_constellation_points(cnst, pts);
     int k = orc_bits_per_symbol(cnst);

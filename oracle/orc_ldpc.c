@@ -237,27 +237,138 @@ int orc_ldpc_decode(const orc_ldpc* c, const float* llr, int max_it, float sigma
     return c->K;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * PRODUCTION ("fast") arithmetic of the decoder (SURVEY 7 "Hard parts" 2; NOT the reference's bits).
+ * The same sum-product recursion in the same likelihood-ratio domain and in double, algebraically
+ * identical to awgn_bp, with 2 divisions per CHECK per iteration instead of 4 per EDGE:
+ *   - the d quotients of a row that share the form x_j / a_j take ONE division: prefix products
+ *     P_j = a_0 .. a_j, I = 1 / P_{d-1}, then 1/a_j = I P_{j-1} walking back with I <- I a_j;
+ *   - extrinsic products are prefix x suffix products instead of (full product) / own factor.
+ * Everything is a plain IEEE double operation in the order written here (the HIP kernel executes the
+ * same sequence; a row / column padded with the neutral element multiplies by exactly 1.0).  Bounded
+ * messages keep every intermediate finite (the reference's form turns a saturated product into 0/inf and then
+ * NaN, whose decision is 0 whatever was sent -- its error floor): channel LLR clamped to +-40, check-node
+ * products to +-(1 - 2^-20) (check-to-variable LLR within +-14.6: the clipping also helps in the waterfall),
+ * variable-to-check ratios to [2^-100, 2^100]; fmin/fmax return the non-NaN operand.
+ * ------------------------------------------------------------------------------------------- */
+#define ORC_FAST_LLR_MAX 40.0f
+#define ORC_FAST_P_MAX (1.0 - 0x1p-20)
+#define ORC_FAST_Q_MAX 0x1p+100
+#define ORC_FAST_Q_MIN 0x1p-100
+#define ORC_FAST_MAX_DEG 64
+
+/* out[j] = num[j] / den[j], j < d, with one division (see above) */
+static void batch_quotients(const double* num, const double* den, int d, double* out)
+{
+    double P[ORC_FAST_MAX_DEG];
+    P[0] = den[0];
+    for (int j = 1; j < d; j++) P[j] = P[j - 1] * den[j];
+    double I = 1 / P[d - 1];
+    for (int j = d - 1; j >= 1; j--) {
+        out[j] = num[j] * (I * P[j - 1]);
+        I = I * den[j];
+    }
+    out[0] = num[0] * I;
+}
+
+int orc_ldpc_decode_fast(const orc_ldpc* c, const float* llr, int max_it, float sigma,
+                         uint8_t* out, int* nit)
+{
+    const int N = c->N, M = c->M, E = c->E;
+    float* y = (float*)malloc(N * sizeof(float));
+    uint8_t* est = (uint8_t*)malloc(N);
+    for (int i = 0; i < N; i++) y[c->permute[i]] = -1 * llr[i];
+    *nit = 0;
+    for (int i = 0; i < N; i++) est[i] = (y[i] < 0) ? 1 : 0;
+    if (!is_codeword(c, est)) {
+        double* rx_lr = (double*)malloc(N * sizeof(double));
+        double* Q = (double*)malloc(E * sizeof(double));
+        double* R = (double*)malloc(E * sizeof(double));
+        for (int i = 0; i < N; i++) {
+            float arg = (-1 * 2 * y[i]) / (sigma * sigma);
+            arg = fminf(fmaxf(arg, -ORC_FAST_LLR_MAX), ORC_FAST_LLR_MAX);
+            rx_lr[i] = exp((double)arg);
+        }
+        for (int e = 0; e < E; e++) Q[e] = rx_lr[c->edge_var[e]];
+        while (*nit < max_it) {
+            *nit += 1;
+            for (int chk = 0; chk < M; chk++) {
+                const int e0 = c->row_ptr[chk], d = c->row_ptr[chk + 1] - e0;
+                double a[ORC_FAST_MAX_DEG], b[ORC_FAST_MAX_DEG], t[ORC_FAST_MAX_DEG];
+                double pre[ORC_FAST_MAX_DEG], suf[ORC_FAST_MAX_DEG];
+                if (d <= 0 || d > ORC_FAST_MAX_DEG) continue;
+                for (int j = 0; j < d; j++) { a[j] = 1 + Q[e0 + j]; b[j] = 1 - Q[e0 + j]; }
+                batch_quotients(b, a, d, t);              /* t_j = (1 - Q_j) / (1 + Q_j) = 2/(1+Q_j) - 1 */
+                pre[0] = 1.0;
+                for (int j = 1; j < d; j++) pre[j] = pre[j - 1] * t[j - 1];
+                suf[d - 1] = 1.0;
+                for (int j = d - 2; j >= 0; j--) suf[j] = suf[j + 1] * t[j + 1];
+                for (int j = 0; j < d; j++) {
+                    double p = pre[j] * suf[j];           /* product of the other edges' t */
+                    p = fmin(fmax(p, -ORC_FAST_P_MAX), ORC_FAST_P_MAX);
+                    a[j] = 1 + p; b[j] = 1 - p;
+                }
+                batch_quotients(b, a, d, &R[e0]);         /* R_j = (1 - p_j) / (1 + p_j) */
+            }
+            for (int v = 0; v < N; v++) {
+                const int i0 = c->col_ptr[v], dv = c->col_ptr[v + 1] - i0;
+                double pre[ORC_FAST_MAX_DEG + 1], suf[ORC_FAST_MAX_DEG];
+                if (dv > ORC_FAST_MAX_DEG) continue;
+                pre[0] = rx_lr[v];
+                for (int i = 0; i < dv; i++) pre[i + 1] = pre[i] * R[c->col_edge[i0 + i]];
+                if (dv > 0) suf[dv - 1] = 1.0;
+                for (int i = dv - 2; i >= 0; i--) suf[i] = suf[i + 1] * R[c->col_edge[i0 + i + 1]];
+                for (int i = 0; i < dv; i++) {
+                    double q = pre[i] * suf[i];
+                    Q[c->col_edge[i0 + i]] = fmin(fmax(q, ORC_FAST_Q_MIN), ORC_FAST_Q_MAX);
+                }
+                est[v] = (pre[dv] > 1) ? 1 : 0;           /* decision on the full product */
+            }
+            if (is_codeword(c, est)) break;
+        }
+        free(rx_lr); free(Q); free(R);
+    }
+    for (int i = 0; i < c->K; i++) out[i] = est[c->permute[i + c->rank]];
+    free(y); free(est);
+    return c->K;
+}
+
+int orc_ldpc_decode_arith(const orc_ldpc* c, const float* llr, int max_it, float sigma, int arith,
+                          uint8_t* out, int* nit)
+{
+    return arith ? orc_ldpc_decode_fast(c, llr, max_it, sigma, out, nit)
+                 : orc_ldpc_decode(c, llr, max_it, sigma, out, nit);
+}
+
 struct batch_arg {
+    int arith;
+
     const orc_ldpc* c; const float* llr; int lo, hi, max_it; float sigma; uint8_t* out; int* nit;
 };
 static void* batch_worker(void* p)
 {
     struct batch_arg* a = (struct batch_arg*)p;
     for (int i = a->lo; i < a->hi; i++)
-        orc_ldpc_decode(a->c, a->llr + (size_t)i * a->c->N, a->max_it, a->sigma,
-                        a->out + (size_t)i * a->c->K, &a->nit[i]);
+        orc_ldpc_decode_arith(a->c, a->llr + (size_t)i * a->c->N, a->max_it, a->sigma, a->arith,
+                              a->out + (size_t)i * a->c->K, &a->nit[i]);
     return NULL;
 }
 
 void orc_ldpc_decode_batch(const orc_ldpc* c, const float* llr, int ncw, int max_it,
                            float sigma, uint8_t* out_bits, int* nit, int n_threads)
 {
+    orc_ldpc_decode_batch_arith(c, llr, ncw, max_it, sigma, 0, out_bits, nit, n_threads);
+}
+
+void orc_ldpc_decode_batch_arith(const orc_ldpc* c, const float* llr, int ncw, int max_it,
+                                 float sigma, int arith, uint8_t* out_bits, int* nit, int n_threads)
+{
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
     pthread_t th[64];
     struct batch_arg args[64];
     for (int t = 0; t < n_threads; t++) {
-        args[t] = (struct batch_arg){ c, llr, (int)((long)ncw * t / n_threads),
+        args[t] = (struct batch_arg){ arith, c, llr, (int)((long)ncw * t / n_threads),
                                       (int)((long)ncw * (t + 1) / n_threads), max_it, sigma,
                                       out_bits, nit };
         if (n_threads == 1) batch_worker(&args[t]);

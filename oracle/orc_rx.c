@@ -72,7 +72,7 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
     int expected_frame_no = 0;
     long lost_frames = 0;
     orc_tbdec* tbd = NULL;
-    if (cfg->has_fec && code) tbd = orc_tbdec_new(code, cap, 4, cfg->max_it, cfg->bp_sigma);
+    if (cfg->has_fec && code) { tbd = orc_tbdec_new(code, cap, 4, cfg->max_it, cfg->bp_sigma); orc_tbdec_set_arith(tbd, cfg->arith); }
     o->n_frames = 0; o->n_tbs = 0; o->n_user_bits = 0; o->n_user_bytes = 0;
     int rc = 0;
 
@@ -147,7 +147,7 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
         }
         int bps = orc_bits_per_symbol(hdr.cnst);
         if (cfg->has_fec) {
-            orc_soft_demap(hdr.cnst, ser, ns, snr.noise_lin, cfg->llr_dist_mode, llr);
+            orc_soft_demap(hdr.cnst, ser, ns, snr.noise_lin, cfg->llr_dist_mode | (cfg->arith ? ORC_DEMAP_FAST : 0), llr);
             if (o->llr) {
                 memset(&o->llr[(size_t)fi * cap * 4], 0, (size_t)cap * 4 * sizeof(float));
                 memcpy(&o->llr[(size_t)fi * cap * 4], llr, (size_t)ns * bps * sizeof(float));

@@ -154,6 +154,7 @@ struct orc_tbdec {
     const orc_ldpc* code;
     int frame_capacity, max_bps, max_it;
     float bp_sigma;
+    int arith;
     /* tb_decoder members (tb_decoder.h:29-38) */
     float* rcv;  long rcv_size, rcv_cap;     /* d_tb_buffers[RCV_BUF]; stale contents persist */
     float* full;                             /* d_tb_buffers[FULL_BUF]                        */
@@ -183,6 +184,8 @@ orc_tbdec* orc_tbdec_new(const orc_ldpc* c, int frame_capacity, int max_bps, int
     d->tb_number = -1;
     return d;
 }
+
+void orc_tbdec_set_arith(orc_tbdec* d, int arith) { d->arith = arith; }
 
 void orc_tbdec_free(orc_tbdec* d)
 {
@@ -221,7 +224,7 @@ static void tb_decode(orc_tbdec* d, int tb_len, int* avg_it)
         for (int j = 0; j < k_; j++, rcv_idx++)
             d->full[(long)i * n + ncheck + j] = (rcv_idx < d->rcv_size) ? d->rcv[rcv_idx] : 0.0f;
         int nit = 0;
-        orc_ldpc_decode(d->code, &d->full[(long)i * n], d->max_it, d->bp_sigma, cw_out, &nit);
+        orc_ldpc_decode_arith(d->code, &d->full[(long)i * n], d->max_it, d->bp_sigma, d->arith, cw_out, &nit);
         memcpy(&d->data[d_idx], cw_out, k_); /* reference copies k bits; later codewords overwrite the tail */
         d_idx += k_;
         sum_it += nit;

@@ -10,7 +10,7 @@ ES = {1: 1.0, 2: 0.25, 3: 1.0, 4: 1.0}  # mean symbol energy of each constellati
 
 
 def make_pair(oracle, dtl, fft_len=64, frame_length=20, fec="n_0300_k_0152_gap_03.alist", sync_threshold=0.95,
-              use_sync_correct=True, llr_dist_mode=0):
+              use_sync_correct=True, llr_dist_mode=0, arith="gr_exact"):
     """-> (product ofdm_adaptive_rx_config, oracle Config, oracle Ldpc or None)"""
     if fft_len == 64:
         pcfg = dtl.ofdm_adaptive_rx_config(frame_length=frame_length)
@@ -19,6 +19,7 @@ def make_pair(oracle, dtl, fft_len=64, frame_length=20, fec="n_0300_k_0152_gap_0
     pcfg.sync_threshold = sync_threshold
     pcfg.use_sync_correct = use_sync_correct
     pcfg.llr_dist_mode = llr_dist_mode
+    pcfg.arith = arith
     if fec:
         pcfg.fec_codes = (("fec_1", fec),)
         pcfg.mcs = ((-100000, (dtl.constellation_type_t.BPSK, "fec_1")), (11, (dtl.constellation_type_t.QPSK, "fec_1")),
@@ -28,7 +29,7 @@ def make_pair(oracle, dtl, fft_len=64, frame_length=20, fec="n_0300_k_0152_gap_0
                          sync_threshold=sync_threshold, use_sync_correct=use_sync_correct,
                          occupied_carriers=pcfg.occupied_carriers, pilot_carriers=pcfg.pilot_carriers,
                          pilot_symbols=pcfg.pilot_symbols, sync_word1=pcfg.sync_word1, sync_word2=pcfg.sync_word2,
-                         llr_dist_mode=llr_dist_mode)
+                         llr_dist_mode=llr_dist_mode, arith={"gr_exact": 0, "fast": 1}[arith])
     code = oracle.Ldpc(os.path.join(CODES, fec)) if fec else None
     return pcfg, ocfg, code
 

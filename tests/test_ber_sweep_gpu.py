@@ -13,20 +13,23 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("snr_db,gap", [(18.0, 0), (24.0, 0), (30.0, 0), (22.0, 64), (28.0, 64)])
-def test_mixed_mcs_1024_sweep_point_matches_oracle(oracle, dtl, cuda, snr_db, gap):
+@pytest.mark.parametrize("snr_db,gap,arith", [(18.0, 0, "gr_exact"), (24.0, 0, "gr_exact"), (30.0, 0, "gr_exact"),
+                                              (22.0, 64, "gr_exact"), (28.0, 64, "gr_exact"), (21.0, 0, "fast"),
+                                              (24.0, 0, "fast")])
+def test_mixed_mcs_1024_sweep_point_matches_oracle(oracle, dtl, cuda, snr_db, gap, arith):
     import torch
     import ber_sweep
     from conftest import CODES
     from gr_dtl_amd.link_sim import bit_errors
-    cfg = ber_sweep.make_config(dtl, 1024, 10, 0.98, sync_correct=(gap == 0))
+    cfg = ber_sweep.make_config(dtl, 1024, 10, 0.95, sync_correct=(gap == 0), arith=arith)
     acc, y, sent = ber_sweep.sweep_point(dtl, cfg, snr_db, 6, 77, cuda, gap=gap)
     rx = dtl.ofdm_receiver(cfg)
     res = rx.work(torch.from_numpy(y).to(cuda))
     ocfg = oracle.Config(fft_len=cfg.fft_len, cp_len=cfg.cp_len, frame_length=cfg.frame_length, has_fec=True,
                          sync_threshold=cfg.sync_threshold, use_sync_correct=cfg.use_sync_correct,
                          occupied_carriers=cfg.occupied_carriers, pilot_carriers=cfg.pilot_carriers,
-                         pilot_symbols=cfg.pilot_symbols, sync_word1=cfg.sync_word1, sync_word2=cfg.sync_word2)
+                         pilot_symbols=cfg.pilot_symbols, sync_word1=cfg.sync_word1, sync_word2=cfg.sync_word2,
+                         arith={"gr_exact": 0, "fast": 1}[arith])
     code = oracle.Ldpc(os.path.join(CODES, "n_0300_k_0152_gap_03.alist"))
     ref = oracle.rx_stream(ocfg, code, y, feedback=oracle_feedback(oracle, cfg, rx), want=("frames",))
     assert len(res.frames) == ref["n_frames"]

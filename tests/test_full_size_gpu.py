@@ -44,7 +44,10 @@ def test_c2_full_batch_matches_oracle(oracle, dtl, cuda):
 def test_c3_full_size_properties(oracle, dtl, cuda):
     import torch
     import bench
-    w = bench.WORKLOADS["c3"]
+    # the bench's C3 stream at an Es/N0 where most transport blocks pass their CRC (the bench line itself runs at the
+    # lowest Es/N0 that synchronises, where the round-trip property has nothing to check)
+    w = dict(bench.WORKLOADS["c3"], esn0_db=23.0)
+    assert w["sync_threshold"] == 0.95
     cfg = bench.build_config(dtl, w)
     rx = dtl.ofdm_receiver(cfg)
     x, n_frames, n_user, user_t = bench.synth_stream(dtl, cfg, w, w["frames"], cuda, seed=0)
@@ -56,10 +59,10 @@ def test_c3_full_size_properties(oracle, dtl, cuda):
     # -- triggers: strictly increasing, dominated by the frame period
     d = np.diff(res.raw_triggers)
     assert (d > 0).all() and np.median(d) == rx.frame_samples
-    assert len(res.frames) >= 0.9 * n_frames
+    assert res.n_payload_frames >= 0.99 * n_frames
     # -- every CRC-ok TB carries exactly what was sent in it
     ok = res.tbs[res.tbs["crc_ok"] == 1]
-    assert len(ok) >= 0.7 * len(res.tbs) > 40000
+    assert len(ok) >= 0.85 * len(res.tbs) > 40000
     # the header carries the block number modulo 256: unwrap it along the stream (fewer than 256 blocks are
     # ever lost in a row), then compare each delivered block with the bytes that were sent in that block
     idx = np.zeros(len(res.tbs), dtype=np.int64)

@@ -117,7 +117,7 @@ def test_fec_chain_matches_oracle_64(oracle, dtl, cuda, cnst, esn0, nbytes):
     pcfg, ocfg, code = make_pair(oracle, dtl)
     user, hdrs, x = make_stream(oracle, ocfg, code, cnst, nbytes, esn0, seed=100 + cnst)
     rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
-    assert ref["n_frames"] >= 0.9 * len(hdrs)
+    assert ref["n_frames"] >= 0.99 * len(hdrs)
     _compare(rx, res, ref, ocfg, True)
     if esn0 is None:
         assert np.array_equal(ref["user_bytes"], user)
@@ -131,7 +131,7 @@ def test_plain_distance_llr_mode(oracle, dtl, cuda, cnst, esn0):
     pcfg, ocfg, code = make_pair(oracle, dtl, llr_dist_mode=1)
     user, hdrs, x = make_stream(oracle, ocfg, code, cnst, 5000, esn0, seed=300 + cnst)
     rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
-    assert ref["n_frames"] >= 0.9 * len(hdrs)
+    assert ref["n_frames"] >= 0.99 * len(hdrs)
     _compare(rx, res, ref, ocfg, True)
 
 
@@ -148,13 +148,15 @@ def test_no_fec_chain_matches_oracle(oracle, dtl, cuda):
 
 @pytest.mark.gpu
 # 128 and 512 have an odd number of butterfly stages (the plain last pass of the two-stages-per-pass FFT)
-@pytest.mark.parametrize("fft_len,frame_length,thr,esn0", [(128, 20, 0.97, 24.0), (256, 20, 0.985, 24.0),
-                                                          (512, 12, 0.985, 25.0), (1024, 10, 0.99, 27.0)])
+# (the receiver's default sync_threshold 0.95 everywhere: with the demux leaving the last payload item unconsumed,
+# a trigger one sample early no longer costs the frame)
+@pytest.mark.parametrize("fft_len,frame_length,thr,esn0", [(128, 20, 0.95, 24.0), (256, 20, 0.95, 24.0),
+                                                          (512, 12, 0.95, 25.0), (1024, 10, 0.95, 27.0)])
 def test_fec_chain_matches_oracle_large_fft(oracle, dtl, cuda, fft_len, frame_length, thr, esn0):
     pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, sync_threshold=thr)
     user, hdrs, x = make_stream(oracle, ocfg, code, 4, {128: 20000, 256: 40000, 512: 50000, 1024: 60000}[fft_len], esn0, seed=fft_len)
     rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
-    assert ref["n_frames"] > 0.5 * len(hdrs)
+    assert ref["n_frames"] >= 0.99 * len(hdrs)
     _compare(rx, res, ref, ocfg, True)
 
 

@@ -14,11 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def make_config(dtl, fft_len, frame_length, threshold, sync_correct=True):
+def make_config(dtl, fft_len, frame_length, threshold, sync_correct=True, arith="gr_exact"):
     cfg = dtl.ofdm_adaptive_rx_config(frame_length=frame_length) if fft_len == 64 else \
         dtl.make_scaled_rx_config(fft_len, frame_length=frame_length)
     cfg.sync_threshold = threshold
     cfg.use_sync_correct = sync_correct
+    cfg.arith = arith
     cfg.fec_codes = (("fec_1", "n_0300_k_0152_gap_03.alist"),)
     C = dtl.constellation_type_t
     cfg.mcs = ((-100000, (C.BPSK, "fec_1")), (11, (C.QPSK, "fec_1")), (16, (C.PSK8, "fec_1")), (21, (C.QAM16, "fec_1")))
@@ -57,7 +58,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fft", type=int, default=1024)
     ap.add_argument("--frame-length", type=int, default=10)
-    ap.add_argument("--threshold", type=float, default=0.98)
+    ap.add_argument("--threshold", type=float, default=0.95)
+    ap.add_argument("--arith", default="gr_exact", choices=("gr_exact", "fast"))
     ap.add_argument("--snr", default="14:32:2", help="start:stop:step in dB (stop exclusive)")
     ap.add_argument("--frames-per-mcs", type=int, default=24)
     ap.add_argument("--seed", type=int, default=2024)
@@ -69,7 +71,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("ber_sweep.py needs a HIP device: the product path has no CPU fallback")
     device = torch.device("cuda", 0)
-    cfg = make_config(dtl, args.fft, args.frame_length, args.threshold, sync_correct=(args.gap == 0))
+    cfg = make_config(dtl, args.fft, args.frame_length, args.threshold, sync_correct=(args.gap == 0), arith=args.arith)
     lo, hi, st = (float(v) for v in args.snr.split(":"))
     points = []
     snr = lo
@@ -82,7 +84,7 @@ def main():
     doc = dict(workload="mixed-MCS (BPSK/QPSK/8PSK/16QAM cycling) AWGN stream, %d-point FFT, LDPC(300,152), "
                         "%d frames per MCS segment" % (args.fft, args.frames_per_mcs),
                snr_definition="noise variance per time-domain sample = fft_len / 10^(snr/10)",
-               sync_threshold=args.threshold, frame_length=args.frame_length, seed=args.seed, gap=args.gap,
+               sync_threshold=args.threshold, arith=args.arith, frame_length=args.frame_length, seed=args.seed, gap=args.gap,
                use_sync_correct=(args.gap == 0), points=points)
     text = json.dumps(doc, indent=1)
     if args.out:
