@@ -165,21 +165,24 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// Index tables of the node-parallel kernel use FIXED strides: check c owns message slots c*MAXR .. c*MAXR+MAXR-1
+// Index tables of the node-parallel kernel use FIXED strides: check c owns message slots j*m + c, j < MAXR -- entry-major,
+// so that the lanes of a check pass (lane == check) touch consecutive doubles: conflict-free LDS reads and writes; a
+// check-major row of 6 doubles (48 bytes) puts lanes l and l+16 on one bank --
 // (rows shorter than MAXR are padded), variable v owns four 16-bit slot indices (columns lighter than four
 // entries are padded).  Padding costs no branch: a padded row slot names the dummy variable n, whose channel
 // LR is 0 and whose hard decision is 0 -- its message stays 0, i.e. the factor 2/(1+0)-1 == 1 in the row
 // product -- and a padded column entry names the message slot kept at 1.0 (factor 1 in the column product)
-// while its write is redirected to a trash slot.  Multiplying by exactly 1.0 changes no bit of a product, so
+// (set back to 1.0 behind the writes of every variable pass).  Multiplying by exactly 1.0 changes no bit of a product, so
 // the arithmetic is still the reference's, without per-edge degree tests and without row/column pointer reads.
 // FAST (dtl_ldpc_set_arith(h, DTL_ARITH_FAST); NOT the reference's bits -- oracle: orc_ldpc_decode_fast): the same
 // recursion with ONE division per batch of a row's quotients (prefix products, one reciprocal, walk back) and prefix x
 // suffix extrinsic products instead of (full product) / own factor: 2 divisions per check per iteration instead of
-// 4 per edge.  Channel LLR, check-node products and variable-to-check ratios are clamped so that every intermediate
-// stays finite (the reference's form saturates to 0 / inf and then NaN, whose decision is 0 whatever was sent).
+// 4 per edge.  The channel LLR (+-40) and the check-node products (+-(1 - 2^-20)) are clamped: check-to-variable
+// ratios then lie in [2^-21, 2^21], variable-to-check ratios below 2^121 for column weights <= 4, a row's product
+// of (1 + Q) below 2^968 for row weights <= 8 -- every intermediate stays finite (the reference's form saturates to
+// 0 / inf and then NaN, whose decision is 0 whatever was sent).
 constexpr float kFastLlrMax = 40.0f;
 constexpr double kFastPMax = 1.0 - 0x1p-20;
-constexpr double kFastQMax = 0x1p+100, kFastQMin = 0x1p-100;
 
 // out[j] = num[j] / den[j], j < D, with one division: P_j = den_0 .. den_j, I = 1 / P_{D-1}, then
 // 1 / den_j = I P_{j-1}, I <- I den_j walking back (the operation order of the oracle's batch_quotients)
@@ -197,6 +200,24 @@ __device__ __forceinline__ void batch_quotients(const double (&num)[D], const do
         I = I * den[j];
     }
     out[0] = num[0] * I;
+}
+
+// a / b for the quotient (row product) / (own factor) of the exact check update: the IEEE double division sequence
+// the compiler emits (v_rcp_f64, two Newton steps, quotient, residual, final fused multiply-add) WITHOUT
+// v_div_scale / v_div_fixup -- same bits whenever those two would do nothing.  Here they never do: a factor is
+// t = 2/(1+q) - 1, so 0 or 2^-53 <= |t| <= 2^54 (or +-inf / NaN), the product of at most 8 of them lies in
+// [2^-424, 2^432]: no operand or quotient is near the over/underflow ranges the scaling handles, and the only
+// special cases are 0/0, inf/inf and NaN operands, which come out as NaN from this sequence as from the full one.
+__device__ __forceinline__ double div_row_product(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = a * r;
+    const double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
 }
 
 template <int MAXR, int MAXC, int NV, bool ROWS_FULL, bool FAST>
@@ -229,11 +250,11 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char* mine = np_smem + sh.wave_base + size_t(wave) * sh.wave_stride;
-    double* msg = reinterpret_cast<double*>(mine);   // n_slots messages + [n_slots] == 1.0 + [n_slots + 1] trash
+    double* msg = reinterpret_cast<double*>(mine);   // n_slots messages + [n_slots] == 1.0 (+ one spare)
     double* rx = msg + n_slots + 2;                  // n channel LRs + rx[n] == 0 (dummy variable)
     uint8_t* est = reinterpret_cast<uint8_t*>(rx + t.n + 1); // n hard decisions + est[n] == 0
     float* ybuf = reinterpret_cast<float*>(msg);
-    const int kOneSlot = n_slots, kTrashSlot = n_slots + 1;
+    const int kOneSlot = n_slots;
     const int ncheck = t.n - t.k;
     const float s2 = sigma * sigma;
 
@@ -303,19 +324,19 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         for (; c0 + kWave <= t.m || t.m - c0 > kWave / 2; c0 += kWave) {
             const int c = c0 + lane;
             if (c < t.m) {
-                double* row = msg + c * MAXR;
+                double* row = msg + c;                    // message j of check c: row[j * t.m] (see the layout note)
                 double tt[MAXR];
 #pragma unroll
-                for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + (FIRST ? rx[chk_var[c * MAXR + j]] : row[j])) - 1;
+                for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + (FIRST ? rx[chk_var[c * MAXR + j]] : row[j * t.m])) - 1;
                 double product = 1.0;
 #pragma unroll
                 for (int j = 0; j < MAXR; j++) product = product * tt[j];
                 const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
 #pragma unroll
                 for (int j = 0; j < MAXR; j++) {
-                    const double prd = product / tt[j];
+                    const double prd = div_row_product(product, tt[j]);
                     const double val = (1 - prd) / (1 + prd);
-                    row[j] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
+                    row[j * t.m] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
                 }
             }
         }
@@ -324,11 +345,11 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             const int c = c0 + (lane >> 1);
             const bool upper = lane & 1;
             const bool valid = c < t.m;
-            double* row = msg + (valid ? c : 0) * MAXR + (upper ? HR : 0);
+            double* row = msg + (valid ? c : 0) + (upper ? HR : 0) * t.m;
             double tt[HR];
 #pragma unroll
             for (int j = 0; j < HR; j++)
-                tt[j] = 2 / (1 + (FIRST ? rx[chk_var[(valid ? c : 0) * MAXR + (upper ? HR : 0) + j]] : row[j])) - 1;
+                tt[j] = 2 / (1 + (FIRST ? rx[chk_var[(valid ? c : 0) * MAXR + (upper ? HR : 0) + j]] : row[j * t.m])) - 1;
             double part = 1.0;
 #pragma unroll
             for (int j = 0; j < HR; j++) part = part * tt[j];             // even lane: ((1 t0) t1) t2
@@ -341,9 +362,9 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < HR; j++) {
-                    const double prd = product / tt[j];
+                    const double prd = div_row_product(product, tt[j]);
                     const double val = (1 - prd) / (1 + prd);
-                    row[j] = (ROWS_FULL || (upper ? HR : 0) + j < deg) ? val : 0.0;
+                    row[j * t.m] = (ROWS_FULL || (upper ? HR : 0) + j < deg) ? val : 0.0;
                 }
             }
         }
@@ -355,12 +376,12 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         for (int c0 = 0; c0 < t.m; c0 += kWave) {
             const int c = c0 + lane;
             if (c < t.m) {
-                double* row = msg + c * MAXR;
+                double* row = msg + c;
                 const int deg = ROWS_FULL ? MAXR : int(chk_deg[c]);
                 double a[MAXR], b[MAXR], tt[MAXR];
 #pragma unroll
                 for (int j = 0; j < MAXR; j++) {
-                    const double q = FIRST ? rx[chk_var[c * MAXR + j]] : row[j];
+                    const double q = FIRST ? rx[chk_var[c * MAXR + j]] : row[j * t.m];
                     a[j] = 1 + q;
                     b[j] = 1 - q;
                 }
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                 }
                 batch_quotients<MAXR>(b, a, tt);          // R_j = (1 - p_j) / (1 + p_j)
 #pragma unroll
-                for (int j = 0; j < MAXR; j++) row[j] = (ROWS_FULL || j < deg) ? tt[j] : 0.0;
+                for (int j = 0; j < MAXR; j++) row[j * t.m] = (ROWS_FULL || j < deg) ? tt[j] : 0.0;
             }
         }
     };
@@ -427,7 +448,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             wave_sync();
             // spa_initialize (Q_e = channel LR of the edge's variable) is folded into the first check pass, which reads
             // rx through the row's variable indices instead of the message slots
-            if (lane == 0) { msg[kOneSlot] = 1.0; msg[kTrashSlot] = 0.0; }
+            if (lane == 0) msg[kOneSlot] = 1.0;
             wave_sync();
             while (nit < max_it) {
                 nit += 1;
@@ -439,7 +460,11 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                     else check_phase(std::false_type{});
                 }
                 wave_sync();
-                // ---- update_vars + decision: lane == variable node
+                // ---- update_vars + decision: lane == variable node.  var_edge holds BYTE offsets of a variable's
+                // message slots; a padded entry names the slot kept at 1.0 and is written like the others -- every
+                // lane's reads of a pass precede its writes (one wave, program order), and the slot is set back to
+                // 1.0 behind the writes of each pass (one uniform store instead of a compare + select per entry)
+                unsigned char* msg_b = reinterpret_cast<unsigned char*>(msg);
                 for (int v = lane; v < t.n; v += kWave) {
                     const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
                     int ee[MAXC];
@@ -451,30 +476,28 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
 #pragma unroll
                         for (int i = 0; i < MAXC; i++) {
                             ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
-                            rr[i] = msg[ee[i]];
+                            rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
                             pre[i + 1] = pre[i] * rr[i];
                         }
                         suf[MAXC - 1] = 1.0;
 #pragma unroll
                         for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
 #pragma unroll
-                        for (int i = 0; i < MAXC; i++) {
-                            const double q = pre[i] * suf[i];
-                            msg[ee[i] == kOneSlot ? kTrashSlot : ee[i]] = fmin(fmax(q, kFastQMin), kFastQMax);
-                        }
+                        for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = pre[i] * suf[i];
                         est[v] = (pre[MAXC] > 1) ? 1 : 0;
-                        continue;
-                    }
-                    double sum = rx[v];
+                    } else {
+                        double sum = rx[v];
 #pragma unroll
-                    for (int i = 0; i < MAXC; i++) {
-                        ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
-                        rr[i] = msg[ee[i]];
-                        sum = sum * rr[i];
-                    }
+                        for (int i = 0; i < MAXC; i++) {
+                            ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
+                            rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
+                            sum = sum * rr[i];
+                        }
 #pragma unroll
-                    for (int i = 0; i < MAXC; i++) msg[ee[i] == kOneSlot ? kTrashSlot : ee[i]] = sum / rr[i];
-                    est[v] = (sum > 1) ? 1 : 0;
+                        for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = sum / rr[i];
+                        est[v] = (sum > 1) ? 1 : 0;
+                    }
+                    msg[kOneSlot] = 1.0;
                 }
                 wave_sync();
                 if (syndrome_ok()) break;
@@ -544,13 +567,14 @@ int LdpcDecoder::upload()
         if (deg != maxr) rows_full = false;
         for (int j = 0; j < deg && j < maxr; j++) {
             chk_var[size_t(c) * maxr + j] = uint16_t(code.edge_var[code.row_ptr[c] + j]);
-            slot_of_edge[code.row_ptr[c] + j] = c * maxr + j;
+            slot_of_edge[code.row_ptr[c] + j] = j * code.m + c;   // entry-major message layout
         }
     }
-    std::vector<uint16_t> var_edge(size_t(code.n) * 4, uint16_t(n_slots));     // pad -> the slot kept at 1.0
+    // BYTE offsets of the message slots (8 bytes each; n_slots * 8 < 65536 is checked below)
+    std::vector<uint16_t> var_edge(size_t(code.n) * 4, uint16_t(n_slots * 8)); // pad -> the slot kept at 1.0
     for (int v = 0; v < code.n; v++)
         for (int i = code.col_ptr[v]; i < code.col_ptr[v + 1] && i - code.col_ptr[v] < 4; i++)
-            var_edge[size_t(v) * 4 + (i - code.col_ptr[v])] = uint16_t(slot_of_edge[code.col_edge[i]]);
+            var_edge[size_t(v) * 4 + (i - code.col_ptr[v])] = uint16_t(slot_of_edge[code.col_edge[i]] * 8);
     size_t o_cv = put(chk_var.data(), chk_var.size() * 2);
     size_t o_ve = put(var_edge.data(), var_edge.size() * 2);
     size_t o_cd = put(chk_deg.data(), chk_deg.size());
@@ -587,7 +611,7 @@ int LdpcDecoder::upload()
         // per-wave slice: padded message slots + 2, channel LRs + 1, hard decisions + 1
         np_sh_.wave_stride = int(al(size_t(n_slots + 2) * 8 + size_t(code.n + 1) * 8 + size_t(code.n + 1)));
         np_lds_ = off + size_t(kNpWaves) * np_sh_.wave_stride;
-        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && n_slots + 2 < 65535 &&
+        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && (n_slots + 2) * 8 < 65535 &&
                  np_lds_ <= 160 * 1024;
         if (np_ok_) {
             for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, true, false>),

@@ -248,13 +248,13 @@ int orc_ldpc_decode(const orc_ldpc* c, const float* llr, int max_it, float sigma
  * same sequence; a row / column padded with the neutral element multiplies by exactly 1.0).  Bounded
  * messages keep every intermediate finite (the reference's form turns a saturated product into 0/inf and then
  * NaN, whose decision is 0 whatever was sent -- its error floor): channel LLR clamped to +-40, check-node
- * products to +-(1 - 2^-20) (check-to-variable LLR within +-14.6: the clipping also helps in the waterfall),
- * variable-to-check ratios to [2^-100, 2^100]; fmin/fmax return the non-NaN operand.
+ * products to +-(1 - 2^-20) (check-to-variable ratios in [2^-21, 2^21], LLR within +-14.6: the clipping also
+ * helps in the waterfall).  Variable-to-check ratios then stay below 2^121 for column weights <= 4 and a row's
+ * product of (1 + Q) below 2^968 for row weights <= 8 (the product's kernel limits).  fmin/fmax return the
+ * non-NaN operand.
  * ------------------------------------------------------------------------------------------- */
 #define ORC_FAST_LLR_MAX 40.0f
 #define ORC_FAST_P_MAX (1.0 - 0x1p-20)
-#define ORC_FAST_Q_MAX 0x1p+100
-#define ORC_FAST_Q_MIN 0x1p-100
 #define ORC_FAST_MAX_DEG 64
 
 /* out[j] = num[j] / den[j], j < d, with one division (see above) */
@@ -318,10 +318,7 @@ int orc_ldpc_decode_fast(const orc_ldpc* c, const float* llr, int max_it, float 
                 for (int i = 0; i < dv; i++) pre[i + 1] = pre[i] * R[c->col_edge[i0 + i]];
                 if (dv > 0) suf[dv - 1] = 1.0;
                 for (int i = dv - 2; i >= 0; i--) suf[i] = suf[i + 1] * R[c->col_edge[i0 + i + 1]];
-                for (int i = 0; i < dv; i++) {
-                    double q = pre[i] * suf[i];
-                    Q[c->col_edge[i0 + i]] = fmin(fmax(q, ORC_FAST_Q_MIN), ORC_FAST_Q_MAX);
-                }
+                for (int i = 0; i < dv; i++) Q[c->col_edge[i0 + i]] = pre[i] * suf[i];
                 est[v] = (pre[dv] > 1) ? 1 : 0;           /* decision on the full product */
             }
             if (is_codeword(c, est)) break;
