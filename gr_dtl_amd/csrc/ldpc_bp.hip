@@ -207,7 +207,11 @@ __device__ __forceinline__ void batch_quotients(const double (&num)[D], const do
 // v_div_scale / v_div_fixup -- same bits whenever those two would do nothing.  Here they never do: a factor is
 // t = 2/(1+q) - 1, so 0 or 2^-53 <= |t| <= 2^54 (or +-inf / NaN), the product of at most 8 of them lies in
 // [2^-424, 2^432]: no operand or quotient is near the over/underflow ranges the scaling handles, and the only
-// special cases are 0/0, inf/inf and NaN operands, which come out as NaN from this sequence as from the full one.
+// special cases are 0/0, inf/inf and NaN operands, which come out as NaN from this sequence as from the full one,
+// a zero product over a non-zero factor, which comes out as +0 where IEEE gives +-0, and an infinite product (a
+// factor 2/0 - 1) over a finite factor, which comes out as NaN where IEEE gives inf -- neither is observable: the
+// quotient's one consumer is R = (1 - prd) / (1 + prd), which is 1 resp. NaN either way.
+// (tools/bp_div_check.hip compares through R: 5 x 10^10 operand pairs per division site, profiles/r02/bp_div_check.txt.)
 __device__ __forceinline__ double div_row_product(double a, double b)
 {
     double r = __builtin_amdgcn_rcp(b);
@@ -219,6 +223,34 @@ __device__ __forceinline__ double div_row_product(double a, double b)
     const double rem = __builtin_fma(-b, q, a);
     return __builtin_fma(rem, r, q);
 }
+
+// a / b, IEEE double.  TAME == false: the compiler's sequence (v_div_scale x 2, v_rcp_f64, Newton, v_div_fmas,
+// v_div_fixup: 11 instructions).  TAME == true: the same sequence without the two v_div_scale and with a plain
+// fused multiply-add for v_div_fmas (9 instructions) -- v_div_fixup still settles zero / infinite / NaN operands.
+// Scaling only moves operands away from the over/underflow ranges by exact powers of two, so the two forms give the
+// same bits whenever no intermediate of the unscaled one leaves the normal range.  For a codeword whose channel
+// exponents all satisfy |arg| <= 500 ("tame": rx in [2^-722, 2^722]) that holds for every division of the exact
+// update: every finite check-to-variable ratio is 0 or has magnitude in [2^-54, 2^54] (a quotient of (1 -+ prd) with
+// prd a multiple of 2^-53 near +-1, or near -1 for |prd| large), so a column product is 0 or within
+// [2^-884, 2^884], a variable-to-check ratio within [2^-938, 2^938], 1 + Q is 0 or within [2^-53, 2^939], and the
+// reciprocals, quotients and residuals (>= 2^-53 x the numerator) of all of them are normal numbers.
+template <bool TAME>
+__device__ __forceinline__ double div_exact(double a, double b)
+{
+    if constexpr (!TAME) {
+        return a / b;
+    } else {
+        double r = __builtin_amdgcn_rcp(b);
+        double e = __builtin_fma(-b, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-b, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        const double q = a * r;
+        const double rem = __builtin_fma(-b, q, a);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), b, a);
+    }
+}
+constexpr float kTameArgMax = 500.0f;
 
 template <int MAXR, int MAXC, int NV, bool ROWS_FULL, bool FAST>
 __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables t, NpShared sh,
@@ -313,8 +345,9 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         }
         return chunk_next++;
     };
-    auto check_phase = [&](auto first) {
+    auto check_phase = [&](auto first, auto tame) {
         constexpr bool FIRST = decltype(first)::value;
+        constexpr bool TAME = decltype(tame)::value;
         // ---- update_chks: lane == check node.  When the last pass would fill at most half of the wave
         // (148 checks = 64 + 64 + 20), it runs with TWO lanes per check instead, each owning half of the
         // row: half the divisions per lane, and the row product is still formed in the reference's
@@ -327,7 +360,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                 double* row = msg + c;                    // message j of check c: row[j * t.m] (see the layout note)
                 double tt[MAXR];
 #pragma unroll
-                for (int j = 0; j < MAXR; j++) tt[j] = 2 / (1 + (FIRST ? rx[chk_var[c * MAXR + j]] : row[j * t.m])) - 1;
+                for (int j = 0; j < MAXR; j++) tt[j] = div_exact<TAME>(2.0, 1 + (FIRST ? rx[chk_var[c * MAXR + j]] : row[j * t.m])) - 1;
                 double product = 1.0;
 #pragma unroll
                 for (int j = 0; j < MAXR; j++) product = product * tt[j];
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
 #pragma unroll
                 for (int j = 0; j < MAXR; j++) {
                     const double prd = div_row_product(product, tt[j]);
-                    const double val = (1 - prd) / (1 + prd);
+                    const double val = div_exact<TAME>(1 - prd, 1 + prd);
                     row[j * t.m] = (ROWS_FULL || j < deg) ? val : 0.0; // a padded slot keeps the neutral message
                 }
             }
@@ -349,7 +382,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             double tt[HR];
 #pragma unroll
             for (int j = 0; j < HR; j++)
-                tt[j] = 2 / (1 + (FIRST ? rx[chk_var[(valid ? c : 0) * MAXR + (upper ? HR : 0) + j]] : row[j * t.m])) - 1;
+                tt[j] = div_exact<TAME>(2.0, 1 + (FIRST ? rx[chk_var[(valid ? c : 0) * MAXR + (upper ? HR : 0) + j]] : row[j * t.m])) - 1;
             double part = 1.0;
 #pragma unroll
             for (int j = 0; j < HR; j++) part = part * tt[j];             // even lane: ((1 t0) t1) t2
@@ -363,7 +396,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
 #pragma unroll
                 for (int j = 0; j < HR; j++) {
                     const double prd = div_row_product(product, tt[j]);
-                    const double val = (1 - prd) / (1 + prd);
+                    const double val = div_exact<TAME>(1 - prd, 1 + prd);
                     row[j * t.m] = (ROWS_FULL || (upper ? HR : 0) + j < deg) ? val : 0.0;
                 }
             }
@@ -439,9 +472,11 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         wave_sync();
         int nit = 0;
         if (!syndrome_ok()) {
+            bool wild = false;                            // a channel exponent outside the tame range (or NaN)
             for (int v = lane; v < t.n; v += kWave) {
                 float arg = (-1 * 2 * ybuf[v]) / s2;
                 if (FAST) arg = fminf(fmaxf(arg, -kFastLlrMax), kFastLlrMax);
+                wild |= !(fabsf(arg) <= kTameArgMax);
                 rx[v] = exp(double(arg));
             }
             if (lane == 0) rx[t.n] = 0.0;
@@ -450,58 +485,65 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             // rx through the row's variable indices instead of the message slots
             if (lane == 0) msg[kOneSlot] = 1.0;
             wave_sync();
-            while (nit < max_it) {
-                nit += 1;
-                if (FAST) {
-                    if (nit == 1) check_phase_fast(std::true_type{});
-                    else check_phase_fast(std::false_type{});
-                } else {
-                    if (nit == 1) check_phase(std::true_type{});
-                    else check_phase(std::false_type{});
-                }
-                wave_sync();
-                // ---- update_vars + decision: lane == variable node.  var_edge holds BYTE offsets of a variable's
-                // message slots; a padded entry names the slot kept at 1.0 and is written like the others -- every
-                // lane's reads of a pass precede its writes (one wave, program order), and the slot is set back to
-                // 1.0 behind the writes of each pass (one uniform store instead of a compare + select per entry)
-                unsigned char* msg_b = reinterpret_cast<unsigned char*>(msg);
-                for (int v = lane; v < t.n; v += kWave) {
-                    const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
-                    int ee[MAXC];
-                    double rr[MAXC];
+            auto iterate = [&](auto tame) {
+                constexpr bool TAME = decltype(tame)::value;
+                while (nit < max_it) {
+                    nit += 1;
                     if (FAST) {
-                        // Q_i = (rx R_0 .. R_{i-1}) (R_{i+1} .. R_{d-1}): prefix x suffix, no division
-                        double pre[MAXC + 1], suf[MAXC];
-                        pre[0] = rx[v];
-#pragma unroll
-                        for (int i = 0; i < MAXC; i++) {
-                            ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
-                            rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
-                            pre[i + 1] = pre[i] * rr[i];
-                        }
-                        suf[MAXC - 1] = 1.0;
-#pragma unroll
-                        for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
-#pragma unroll
-                        for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = pre[i] * suf[i];
-                        est[v] = (pre[MAXC] > 1) ? 1 : 0;
+                        if (nit == 1) check_phase_fast(std::true_type{});
+                        else check_phase_fast(std::false_type{});
                     } else {
-                        double sum = rx[v];
-#pragma unroll
-                        for (int i = 0; i < MAXC; i++) {
-                            ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
-                            rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
-                            sum = sum * rr[i];
-                        }
-#pragma unroll
-                        for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = sum / rr[i];
-                        est[v] = (sum > 1) ? 1 : 0;
+                        if (nit == 1) check_phase(std::true_type{}, tame);
+                        else check_phase(std::false_type{}, tame);
                     }
-                    msg[kOneSlot] = 1.0;
+                    wave_sync();
+                    // ---- update_vars + decision: lane == variable node.  var_edge holds BYTE offsets of a variable's
+                    // message slots; a padded entry names the slot kept at 1.0 and is written like the others -- every
+                    // lane's reads of a pass precede its writes (one wave, program order), and the slot is set back to
+                    // 1.0 behind the writes of each pass (one uniform store instead of a compare + select per entry)
+                    unsigned char* msg_b = reinterpret_cast<unsigned char*>(msg);
+                    for (int v = lane; v < t.n; v += kWave) {
+                        const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
+                        int ee[MAXC];
+                        double rr[MAXC];
+                        if (FAST) {
+                            // Q_i = (rx R_0 .. R_{i-1}) (R_{i+1} .. R_{d-1}): prefix x suffix, no division
+                            double pre[MAXC + 1], suf[MAXC];
+                            pre[0] = rx[v];
+#pragma unroll
+                            for (int i = 0; i < MAXC; i++) {
+                                ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
+                                rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
+                                pre[i + 1] = pre[i] * rr[i];
+                            }
+                            suf[MAXC - 1] = 1.0;
+#pragma unroll
+                            for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
+#pragma unroll
+                            for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = pre[i] * suf[i];
+                            est[v] = (pre[MAXC] > 1) ? 1 : 0;
+                        } else {
+                            double sum = rx[v];
+#pragma unroll
+                            for (int i = 0; i < MAXC; i++) {
+                                ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
+                                rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
+                                sum = sum * rr[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = div_exact<TAME>(sum, rr[i]);
+                            est[v] = (sum > 1) ? 1 : 0;
+                        }
+                        msg[kOneSlot] = 1.0;
+                    }
+                    wave_sync();
+                    if (syndrome_ok()) break;
                 }
-                wave_sync();
-                if (syndrome_ok()) break;
-            }
+            };
+            // exact arithmetic: the cheaper division form when every channel exponent of this codeword is tame (see
+            // div_exact); the choice is wave-uniform.  The fast arithmetic has no per-edge divisions to save.
+            if (FAST || __ballot(wild) != 0ull) iterate(std::false_type{});
+            else iterate(std::true_type{});
         }
         for (int i = lane; i < k_used; i += kWave) out_bits[size_t(out_off) + i] = est[sys_src[i]];
         if (lane == 0) out_nit[cw] = nit;
