@@ -38,6 +38,9 @@ static_assert(sizeof(dtl_cw_desc) == sizeof(dtl::CwDesc), "C ABI gather descript
 static_assert(sizeof(dtl_rx_frame_info) == sizeof(dtl::FrameInfo), "C ABI frame info layout");
 static_assert(sizeof(dtl_rx_tb_info) == sizeof(dtl::TbInfo), "C ABI TB info layout");
 static_assert(sizeof(dtl_tx_frame_info) == sizeof(dtl::TxFrameInfo), "C ABI TX frame info layout");
+static_assert(sizeof(dtl_header_fields) == sizeof(dtl::HeaderRec), "C ABI header fields layout");
+static_assert(sizeof(dtl_frame_eq_out) == sizeof(dtl::FrameStat), "C ABI frame equaliser output layout");
+static_assert(sizeof(dtl_tb_span) == sizeof(dtl::TbSpan), "C ABI transport-block span layout");
 
 extern "C" {
 
@@ -386,6 +389,78 @@ int dtl_crc32(const uint8_t* d_bytes, int64_t len, uint32_t* crc_host, void* str
     rc = dtl::launch_crc32(d_bytes, len, d_out.as<uint32_t>(), st);
     if (rc != DTL_OK) return rc;
     DTL_HIP_CHECK(hipMemcpyAsync(crc_host, d_out.p, 4, hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    return DTL_OK;
+}
+
+int dtl_chanest(dtl_rx* h, const float* d_sync_syms, int64_t n, int32_t* d_carr_offset, float* d_taps, void* stream)
+{
+    if (!h || n < 0 || n > 0x7fffffff) { dtl::set_last_error("chanest: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
+    return h->rx.chanest(reinterpret_cast<const dtl::cf32*>(d_sync_syms), int(n), d_carr_offset,
+                         reinterpret_cast<dtl::cf32*>(d_taps), static_cast<hipStream_t>(stream));
+}
+
+int dtl_header_decode(dtl_rx* h, const float* d_hdr_syms, const float* d_taps, const int32_t* d_carr_offset, int64_t n,
+                      dtl_header_fields* fields_host, uint8_t* d_hdr_bits, float* d_taps_out, void* stream)
+{
+    if (!h || n < 0 || n > 0x7fffffff) { dtl::set_last_error("header_decode: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
+    return h->rx.header_decode(reinterpret_cast<const dtl::cf32*>(d_hdr_syms), reinterpret_cast<const dtl::cf32*>(d_taps),
+                               d_carr_offset, int(n), reinterpret_cast<dtl::HeaderRec*>(fields_host), d_hdr_bits,
+                               reinterpret_cast<dtl::cf32*>(d_taps_out), static_cast<hipStream_t>(stream));
+}
+
+int dtl_equalize_frames(dtl_rx* h, const float* d_frames, const float* d_taps, const dtl_frame_eq_in* in_host, int64_t n,
+                        float* d_eq_hard, float* d_eq_soft, float* d_soft_syms, dtl_frame_eq_out* out_host, void* stream)
+{
+    if (!h || n < 0 || n > 0x7fffffff || (n > 0 && !in_host)) { dtl::set_last_error("equalize_frames: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
+    std::vector<dtl::FrameDesc> descs(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; i++) {
+        dtl::FrameDesc& d = descs[size_t(i)];
+        d = dtl::FrameDesc{};
+        d.seg = -1; d.cand = int32_t(i); d.cnst = in_host[i].cnst; d.carr_offset = in_host[i].carr_offset;
+        d.n_syms = std::max(0, std::min(in_host[i].n_payload_syms, h->rx.frame_capacity()));
+    }
+    return h->rx.equalize_frames(reinterpret_cast<const dtl::cf32*>(d_frames), reinterpret_cast<const dtl::cf32*>(d_taps),
+                                 descs.data(), int(n), reinterpret_cast<dtl::cf32*>(d_eq_hard),
+                                 reinterpret_cast<dtl::cf32*>(d_eq_soft), reinterpret_cast<dtl::cf32*>(d_soft_syms),
+                                 reinterpret_cast<dtl::FrameStat*>(out_host), static_cast<hipStream_t>(stream));
+}
+
+int dtl_tb_gather(const int32_t* code_n, const int32_t* code_k, int32_t n_codes, int32_t frame_capacity, int32_t max_bps,
+                  const dtl_rx_frame_info* frames_host, int64_t n_frames, dtl_cw_desc* d_cw_desc, int64_t cw_cap,
+                  int64_t* n_cw, dtl_tb_span* spans_host, int64_t span_cap, int64_t* n_spans, void* stream)
+{
+    if (!code_n || !code_k || n_codes <= 0 || frame_capacity <= 0 || max_bps < 1 || max_bps > 4 || n_frames < 0 ||
+        (n_frames > 0 && !frames_host) || !n_cw || !n_spans) {
+        dtl::set_last_error("tb_gather: bad argument");
+        return DTL_ERR_INVALID_ARG;
+    }
+    std::vector<std::pair<int, int>> nk;
+    for (int i = 0; i < n_codes; i++) nk.push_back({ code_n[i], code_k[i] });
+    std::vector<dtl::TbGather> gathers;
+    std::vector<dtl::TbSpan> spans;
+    int rc = dtl::tb_gather_frames(nk, frame_capacity, max_bps, reinterpret_cast<const dtl::FrameInfo*>(frames_host), n_frames,
+                                   gathers, spans);
+    if (rc != DTL_OK) return rc;
+    int64_t total_cw = 0;
+    for (auto& sp : spans) total_cw += sp.n_cw;
+    *n_cw = total_cw;
+    *n_spans = int64_t(spans.size());
+    if (int64_t(spans.size()) > span_cap || total_cw > cw_cap) { dtl::set_last_error("tb_gather: output capacity too small"); return DTL_ERR_CAPACITY; }
+    if (spans.empty()) return DTL_OK;
+    if (!d_cw_desc || !spans_host) { dtl::set_last_error("tb_gather: null output"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
+    std::memcpy(spans_host, spans.data(), spans.size() * sizeof(dtl::TbSpan));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dtl::DevBuf d_g;
+    rc = d_g.ensure(gathers.size() * sizeof(dtl::TbGather));
+    if (rc != DTL_OK) return rc;
+    DTL_HIP_CHECK(hipMemcpyAsync(d_g.p, gathers.data(), gathers.size() * sizeof(dtl::TbGather), hipMemcpyHostToDevice, st));
+    rc = dtl::launch_expand_cw(d_g.as<dtl::TbGather>(), int(gathers.size()), reinterpret_cast<dtl::CwDesc*>(d_cw_desc), st);
+    if (rc != DTL_OK) return rc;
     DTL_HIP_CHECK(hipStreamSynchronize(st));
     return DTL_OK;
 }

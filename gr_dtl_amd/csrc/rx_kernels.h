@@ -31,6 +31,11 @@ int launch_expand_cw(const TbGather* tbs, int n_tbs, CwDesc* out, hipStream_t st
 int launch_nofec_lengths(const int32_t* info, int n, int32_t* len, hipStream_t st);
 int launch_compact(const uint8_t* staging, int stride, const int32_t* len, int n, uint32_t* offs,
                    uint32_t* total, uint8_t* out, hipStream_t st);
+// per-block entry points on frequency-domain vectors (dtl_chanest, dtl_header_decode, dtl_equalize_frames)
+int launch_header_stage(const RxTables& t, int n, const HeaderStageIo& io, HeaderRec* recs, cf32* taps_out,
+                        uint8_t* hdr_bits, hipStream_t st);
+int launch_frame_eq_stage(const RxTables& t, const cf32* freq, const FrameDesc* frames, int n_frames, const cf32* taps,
+                          FrameStat* stats, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, hipStream_t st);
 // stand-alone stages (block shims, unit tests)
 void constellation_points_host(int cnst, cf32* out16);
 int launch_soft_demap(const cf32* syms, int64_t n, int cnst, double noise, int dist_mode, float* llr, hipStream_t st);

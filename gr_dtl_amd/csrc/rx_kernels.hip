@@ -474,10 +474,14 @@ __global__ __launch_bounds__(64) void trigger_angle_kernel(const cf32* __restric
 // (ofdm_frame_equalizer_vcvc around ofdm_adaptive_header_equalizer, alpha == 1), serializer,
 // BPSK slicer, ofdm_adaptive_packet_header::header_parser.
 // ------------------------------------------------------------------------------------------
+// STAGE == true serves the per-block entry points dtl_chanest / dtl_header_decode: the rows come from frequency-domain
+// vectors (what fft_vcc hands the reference's ofdm_chanest_vcvc / header equaliser) instead of being cut out of the
+// IQ stream and transformed here; everything behind the rows is the same code.
+template <bool STAGE>
 __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
                               const Candidate* __restrict__ cands, const CfoSegment* __restrict__ segs,
                               int n_segs, HeaderRec* __restrict__ recs, cf32* __restrict__ taps_out,
-                              uint8_t* __restrict__ hdr_bits_out, int search_in_lds)
+                              uint8_t* __restrict__ hdr_bits_out, int search_in_lds, HeaderStageIo io)
 {
     extern __shared__ unsigned char smem_raw[];
     const int N = t.fft_len, h = t.header_len, tid = threadIdx.x;
@@ -490,10 +494,22 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     __shared__ int s_off;
 
     tw[tid] = t.twiddle[tid];
-    const Candidate cd = cands[blockIdx.x];
-    const SegWindow sw = seg_window(segs, n_segs, cd.seg);
-    for (int s = 0; s < 2 + h; s += 4)
-        load_and_fft4(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, sw, Y + size_t(s) * N, tw);
+    if constexpr (STAGE) {
+        // rows io.row0 .. io.row0 + io.n_rows - 1 from the caller's shifted vectors (DC at N/2); the others are zero
+        const int nat = fft_lds_swizzle((tid + N / 2) & (N - 1));       // where shifted position tid sits in a row
+        for (int r = 0; r < 2 + h; r++) {
+            cf32 v = { 0.0f, 0.0f };
+            if (r >= io.row0 && r < io.row0 + io.n_rows) v = io.freq_in[(size_t(blockIdx.x) * io.n_rows + (r - io.row0)) * N + tid];
+            Y[size_t(r) * N + nat] = v;
+        }
+        __syncthreads();
+    } else {
+        const Candidate cd = cands[blockIdx.x];
+        const SegWindow sw = seg_window(segs, n_segs, cd.seg);
+        for (int s = 0; s < 2 + h; s += 4)
+            load_and_fft4(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, sw, Y + size_t(s) * N, tw);
+    }
+    const bool given_taps = STAGE && io.taps_in != nullptr;     // dtl_header_decode: channel estimate supplied
     // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N] (rows are stored swizzled)
     auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + fft_lds_swizzle((k + N / 2) & (N - 1))]; };
 
@@ -503,7 +519,9 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     // half of the workgroup per offset parity) and park them in LDS, then one lane per offset only adds.
     const int n_g = (t.g_max - t.g_min) / 2 + 1;
     const int n_act = t.n_sync_act;
-    if (search_in_lds) {
+    if (given_taps) {
+        if (tid == 0) s_off = io.carr_off_in[blockIdx.x];
+    } else if (search_in_lds) {
         const int per = n_act <= N / 2 ? N / 2 : N;          // lanes reserved per offset
         const int groups = N / per, grp = tid / per, a = tid - grp * per;
         // two rounds over half of the offsets each: half the LDS for the products, more workgroups per CU
@@ -539,7 +557,7 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && !given_taps) {
         int best = 0;
         float bmax = 0.0f;
         for (int gi = 0; gi < n_g; gi++)
@@ -549,13 +567,21 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     __syncthreads();
     const int off = s_off;
     // get_chan_taps
-    {
+    if (given_taps) {
+        H[tid] = io.taps_in[size_t(blockIdx.x) * N + tid];
+    } else {
         const int j = tid; // tap index
         cf32 tap = { 0.0f, 0.0f };
         const int lo = off > 0 ? 0 : -off, hi = off > 0 ? N - off : N;
         const cf32 r = t.ref_sym[j];
         if (j >= lo && j < hi && cnonzero(r)) tap = cdiv(ysh(1, j + off), r);
         H[j] = tap;
+    }
+    if constexpr (STAGE) {
+        // ofdm_chanest_vcvc's own outputs: the taps of the "ofdm_sync_chan_taps" tag and the carrier offset
+        if (io.taps_raw_out) io.taps_raw_out[size_t(blockIdx.x) * N + tid] = H[tid];
+        if (io.carr_off_out && tid == 0) io.carr_off_out[blockIdx.x] = off;
+        if (!io.do_header) return;
     }
     __syncthreads();
     // header symbols: integer-CFO shift on the flattened frame, phase derotation, one-tap equalise
@@ -778,7 +804,10 @@ __device__ __forceinline__ Welford welford_merge(Welford a, Welford b, const dou
 // into LDS before the batch, the equalised data symbols are parked in LDS and stored after it.  The general form
 // requests its table entries one step ahead and stores from inside the step; the compiler then drains the memory
 // queue once per step (loads and stores share one in-order counter), the staged form once per batch.
-template <bool STAGED>
+// FREQ_IN == true serves the per-block entry point dtl_equalize_frames: `iq` then holds, per frame, the L x N
+// frequency-domain vectors the reference's frame equaliser block receives from fft_vcc (shifted, DC at N/2) and the
+// batches are copied from there instead of being cut out of the IQ stream and transformed.
+template <bool STAGED, bool FREQ_IN = false>
 __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
                                 const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
                                 int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
@@ -947,7 +976,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     if (lag < 0) { stage_begin(); eq_step(0, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row -1: the zero fill of the shift
     for (int i0 = 0; i0 < L; i0 += 4) {
         const int nb = min(4, L - i0);
-        load_and_fft4<DTL_ABLATE>(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
+        if constexpr (FREQ_IN) {
+            const int nat = fft_lds_swizzle((tid + N / 2) & (N - 1));   // where shifted position tid sits in a row
+            for (int u = 0; u < nb; u++) buf[u * N + nat] = iq[(size_t(blockIdx.x) * L + (i0 + u)) * N + tid];
+            __syncthreads();
+        } else {
+            load_and_fft4<DTL_ABLATE>(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
+        }
         stage_begin();
         for (int u = 0; u < nb; u++) {
             const int i = i0 + u - lag;               // destination symbol fed by source row i0 + u
@@ -1397,6 +1432,8 @@ size_t header_lds_bytes(const RxTables& t)
     return (b + 15) & ~size_t(15);
 }
 
+static size_t frame_eq_lds_bytes(const RxTables& t, bool staged);
+
 int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate* cands, int n_cand,
                   const CfoSegment* segs, int n_segs, HeaderRec* recs, cf32* taps, uint8_t* hdr_bits,
                   hipStream_t st)
@@ -1405,12 +1442,44 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
     const size_t lds = header_lds_bytes(t);
     static size_t attr_lds = 64 * 1024;
     if (lds > attr_lds) {
-        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(header_kernel),
+        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(header_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(header_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(header_kernel, dim3(n_cand), dim3(t.fft_len), lds, st, t, iq, n, cands,
-                       segs, n_segs, recs, taps, hdr_bits, header_search_in_lds(t) ? 1 : 0);
+    hipLaunchKernelGGL(header_kernel<false>, dim3(n_cand), dim3(t.fft_len), lds, st, t, iq, n, cands,
+                       segs, n_segs, recs, taps, hdr_bits, header_search_in_lds(t) ? 1 : 0, HeaderStageIo{});
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+// dtl_chanest / dtl_header_decode: n blocks of frequency-domain rows (see HeaderStageIo)
+int launch_header_stage(const RxTables& t, int n, const HeaderStageIo& io, HeaderRec* recs, cf32* taps_out,
+                        uint8_t* hdr_bits, hipStream_t st)
+{
+    if (n <= 0) return DTL_OK;
+    const size_t lds = header_lds_bytes(t);
+    if (lds > 64 * 1024) {
+        DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(header_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    }
+    hipLaunchKernelGGL(header_kernel<true>, dim3(n), dim3(t.fft_len), lds, st, t, nullptr, int64_t(0), nullptr, nullptr, 0,
+                       recs, taps_out, hdr_bits, header_search_in_lds(t) ? 1 : 0, io);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
+// dtl_equalize_frames: n frames of L x N frequency-domain vectors -> sliced / pre-slice symbols, serializer output,
+// SNR estimate.  Always the general (not STAGED) form: the rows are requested by the caller.
+int launch_frame_eq_stage(const RxTables& t, const cf32* freq, const FrameDesc* frames, int n_frames, const cf32* taps,
+                          FrameStat* stats, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, hipStream_t st)
+{
+    if (n_frames <= 0) return DTL_OK;
+    const size_t lds = frame_eq_lds_bytes(t, false);
+    if (lds > 64 * 1024) { set_last_error("frame equaliser: FFT scratch does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL((frame_eq_kernel<false, true>), dim3(n_frames), dim3(t.fft_len), lds, st, t, freq, int64_t(0), frames,
+                       nullptr, 0, taps, stats, eq_hard, eq_soft, soft_syms);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

@@ -69,6 +69,12 @@ static int upload_vec(HostBuf& hb, DevBuf& db, const std::vector<T>& v, hipStrea
     return DTL_OK;
 }
 
+#define DTL_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != DTL_OK) return _rc; \
+    } while (0)
+
 static int bits_per_symbol(int cnst) { return (cnst >= 1 && cnst <= 4) ? cnst : 0; }
 static int compute_tb_len(int cw_len, int frame_len) { return frame_len > cw_len ? 1 + frame_len / cw_len : 1; }
 static int align_bits_to_bytes(int nbits) { return nbits / 8 + ((nbits % 8) ? 1 : 0); }
@@ -308,7 +314,14 @@ struct TbAssembler {
         // reads past the frame's soft bits (reference: whatever follows in the buffer) are
         // defined as "never received": a gap segment, decoded as soft value 0
         const long h2 = std::min(hi, in_len);
-        if (h2 > lo) rcv.push_back({ uint32_t(base + lo), int(h2 - lo) });
+        if (h2 > lo) {
+            // a piece that continues the previous one in the soft-bit stream (consecutive frames used to their last
+            // bit) extends it: a transport block over many short frames stays one segment
+            if (!rcv.empty() && rcv.back().off != 0xFFFFFFFFu && uint64_t(rcv.back().off) + uint64_t(rcv.back().len) == uint64_t(base + lo))
+                rcv.back().len += int(h2 - lo);
+            else
+                rcv.push_back({ uint32_t(base + lo), int(h2 - lo) });
+        }
         if (hi > std::max(h2, lo)) rcv.push_back({ 0xFFFFFFFFu, int(hi - std::max(h2, lo)) });
         rcv_size += hi - lo;
     }
@@ -333,7 +346,95 @@ struct TbAssembler {
     }
 };
 
+struct CodeDims { int n = 0, k = 0; };
+
+// One frame through ofdm_adaptive_fec_decoder_impl::general_work (:80-217) -> tb_decoder::process_frame
+// (tb_decoder.cc:32-141), on index ranges of the soft-bit stream: `base` = stream offset of the frame's first soft
+// bit, n_syms x bps of them present.  dims[fec id] = (n, k) of the code; completed blocks are appended to asmb.done.
+int tb_process_frame(TbAssembler& asmb, const FrameInfo& fi, int cnst, int n_syms, uint32_t base, int capacity,
+                     const std::vector<CodeDims>& dims)
+{
+    if (fi.payload_len == 0) return DTL_OK; // empty frame never reaches the FEC decoder
+    const int bps = bits_per_symbol(cnst);
+    const long in_len = long(n_syms) * bps;
+    if (fi.fec <= 0 || fi.fec >= int(dims.size()) || dims[fi.fec].n <= 0) return DTL_OK; // reference dereferences a null decoder here
+    const int n_ = dims[fi.fec].n, k_ = dims[fi.fec].k, ncheck = n_ - k_;
+    const long frame_payload = 8L * fi.payload_len;           // fec_utils.cc:93
+    const long tb_offset = 8L * fi.tb_offset;                 // fec_decoder_impl.cc:147
+    const int frame_len = 8 * align_bits_to_bytes(capacity * bps); // :207
+    auto info_nk = [&](int& nn, int& kk) { nn = dims[asmb.info_code].n; kk = dims[asmb.info_code].k; };
+    if (fi.tb_no == asmb.tb_number) {
+        if (asmb.buf_idx + frame_payload > asmb.rcv_cap) { set_last_error("rcv buffer does not have enough capacity!"); return DTL_ERR_CAPACITY; }
+        asmb.append(base, 0, frame_payload, in_len);
+        asmb.buf_idx += frame_payload;
+        const int ncws = compute_tb_len(n_, frame_len);
+        if (asmb.rcv_size >= long(ncheck) * ncws + fi.tb_payload) {
+            int nn, kk; info_nk(nn, kk);
+            asmb.decode(ncws, nn, kk, fi.tb_no, fi.tb_payload);
+            asmb.buf_idx = 0; asmb.clear();
+        }
+    } else if (asmb.rcv_size == 0 && tb_offset == frame_payload) {
+        asmb.have_info = true; asmb.info_tb_payload = fi.tb_payload; asmb.info_code = fi.fec;
+        asmb.tb_number = fi.tb_no; asmb.buf_idx = 0; asmb.clear();
+        asmb.append(base, 0, tb_offset, in_len);
+        asmb.decode(compute_tb_len(n_, frame_len), n_, k_, fi.tb_no, fi.tb_payload);
+        asmb.clear();
+    } else {
+        if (tb_offset > 0) asmb.append(base, 0, tb_offset, in_len);
+        if (asmb.rcv_size > 0 && asmb.have_info) {
+            int nn, kk; info_nk(nn, kk);
+            asmb.decode(compute_tb_len(nn, frame_len), nn, kk, asmb.tb_number, asmb.info_tb_payload);
+        }
+        asmb.have_info = true; asmb.info_tb_payload = fi.tb_payload; asmb.info_code = fi.fec;
+        asmb.tb_number = fi.tb_no; asmb.buf_idx = 0; asmb.clear();
+        int extra_bits = 0;
+        if (tb_offset % bps) extra_bits = int(bps - tb_offset % bps);
+        const long new_tb_offset = tb_offset ? tb_offset + extra_bits : 0;
+        asmb.append(base, new_tb_offset, frame_payload + extra_bits, in_len);
+        asmb.buf_idx += frame_payload - tb_offset;
+        const int tb_len = compute_tb_len(n_, frame_len);
+        const long tb_size = 8L * align_bits_to_bytes(tb_len * ncheck + fi.tb_payload);
+        if (frame_payload - tb_offset == tb_size) {
+            asmb.decode(tb_len, n_, k_, fi.tb_no, fi.tb_payload);
+            asmb.buf_idx = 0; asmb.clear();
+        }
+    }
+    return DTL_OK;
+}
+
 } // namespace
+
+// dtl_tb_gather (C ABI): the transport-block reassembly alone, for a self-contained run of frames.  -> gather recipes
+// (one per completed block, with cw_first / bits_off filled in stream order) and the code each block uses.
+int tb_gather_frames(const std::vector<std::pair<int, int>>& code_nk, int capacity, int max_bps, const FrameInfo* frames,
+                     int64_t n_frames, std::vector<TbGather>& gathers, std::vector<TbSpan>& spans)
+{
+    TbAssembler asmb;
+    std::vector<CodeDims> dims(code_nk.size() + 1);
+    int max_n = 0;
+    for (size_t i = 0; i < code_nk.size(); i++) { dims[i + 1] = { code_nk[i].first, code_nk[i].second }; max_n = std::max(max_n, code_nk[i].first); }
+    asmb.rcv_cap = 2L * max_n * compute_tb_len(max_n, capacity * max_bps); // tb_decoder.cc:24-27
+    for (int64_t f = 0; f < n_frames; f++) {
+        const FrameInfo& fi = frames[f];
+        if (!fi.header_ok || fi.llr_offset < 0) continue;
+        const int bps = bits_per_symbol(fi.cnst);
+        if (bps <= 0) { set_last_error("Tags missing"); return DTL_ERR_TAGS_MISSING; } // fec_decoder_impl.cc:121-126
+        const int n_syms = fi.payload_len ? std::min(fi.n_payload_syms, capacity) : 0;
+        DTL_TRY(tb_process_frame(asmb, fi, fi.cnst, n_syms, uint32_t(fi.llr_offset), capacity, dims));
+    }
+    if (asmb.overflow) { set_last_error("transport block spread over more than 4 stream segments"); return DTL_ERR_UNSUPPORTED; }
+    gathers.clear(); spans.clear();
+    uint32_t bits_base = 0, cw_first = 0;
+    for (auto& d : asmb.done) {
+        d.g.bits_off = bits_base;
+        d.g.cw_first = cw_first;
+        bits_base += (uint32_t(d.g.tb_payload) + 15u) & ~7u;
+        gathers.push_back(d.g);
+        spans.push_back({ d.tb_no, d.code, d.g.tb_payload, int(d.g.n_cw), cw_first, d.g.bits_off });
+        cw_first += uint32_t(d.g.n_cw);
+    }
+    return DTL_OK;
+}
 
 // ------------------------------------------------------------------ stream state
 
@@ -425,7 +526,8 @@ int Receiver::init()
         dec->arith = cfg.arith;
         decoders_.push_back(std::move(dec));
     }
-    if (cfg.has_fec && decoders_.size() < 2) { set_last_error("Misconfiguration: decoder not found!"); return DTL_ERR_INVALID_ARG; }
+    // (a handle with has_fec but without codes serves the single-block entry points -- header length 2 -- and is
+    // refused by process(): ofdm_adaptive_fec_decoder_impl.cc "Misconfiguration: decoder not found!")
     if (cfg.mcs.empty()) cfg.mcs = { { DBL_MIN, 1, 0 }, { 13, 2, 0 }, { 18, 3, 0 }, { 23, 4, 0 } }; // config.py:43-44
     return DTL_OK;
 }
@@ -640,11 +742,6 @@ static void sort_edges(std::vector<unsigned long long>& edges)
     }
 }
 
-#define DTL_TRY(expr)                  \
-    do {                               \
-        int _rc = (expr);              \
-        if (_rc != DTL_OK) return _rc; \
-    } while (0)
 
 int Receiver::process(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t st)
 {
@@ -1065,6 +1162,60 @@ int Receiver::stage_triggers(Call& c)
     return DTL_OK;
 }
 
+// ------------------------------------------------------------------ single blocks (frequency-domain vectors in)
+
+int Receiver::chanest(const cf32* d_sync_syms, int n, int32_t* d_carr_off, cf32* d_taps, hipStream_t st)
+{
+    if (n < 0 || (n > 0 && (!d_sync_syms || !d_carr_off || !d_taps))) { set_last_error("chanest: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (!uploaded_) DTL_TRY(upload_tables());
+    HeaderStageIo io;
+    io.freq_in = d_sync_syms; io.n_rows = 2; io.row0 = 0;
+    io.taps_raw_out = d_taps; io.carr_off_out = d_carr_off; io.do_header = 0;
+    return launch_header_stage(tab_, n, io, nullptr, nullptr, nullptr, st);
+}
+
+int Receiver::header_decode(const cf32* d_hdr_syms, const cf32* d_taps, const int32_t* d_carr_off, int n,
+                            HeaderRec* recs_host, uint8_t* d_hdr_bits, cf32* d_taps_out, hipStream_t st)
+{
+    if (n < 0 || (n > 0 && (!d_hdr_syms || !d_taps || !d_carr_off || !recs_host))) { set_last_error("header_decode: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (n == 0) return DTL_OK;
+    if (!uploaded_) DTL_TRY(upload_tables());
+    DevBuf recs, taps_scratch;
+    DTL_TRY(recs.ensure(size_t(n) * sizeof(HeaderRec)));
+    if (!d_taps_out) { DTL_TRY(taps_scratch.ensure(size_t(n) * cfg.fft_len * sizeof(cf32))); d_taps_out = taps_scratch.as<cf32>(); }
+    HeaderStageIo io;
+    io.freq_in = d_hdr_syms; io.n_rows = cfg.header_len(); io.row0 = 2;
+    io.taps_in = d_taps; io.carr_off_in = d_carr_off; io.do_header = 1;
+    DTL_TRY(launch_header_stage(tab_, n, io, recs.as<HeaderRec>(), d_taps_out, d_hdr_bits, st));
+    DTL_HIP_CHECK(hipMemcpyAsync(recs_host, recs.p, size_t(n) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    return DTL_OK;
+}
+
+int Receiver::equalize_frames(const cf32* d_frames, const cf32* d_taps, const FrameDesc* descs_host, int n, cf32* d_hard,
+                              cf32* d_soft, cf32* d_soft_syms, FrameStat* stats_host, hipStream_t st)
+{
+    if (n < 0 || (n > 0 && (!d_frames || !d_taps || !descs_host))) { set_last_error("equalize_frames: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (n == 0) return DTL_OK;
+    for (int i = 0; i < n; i++)
+        if (descs_host[i].cnst < 1 || descs_host[i].cnst > 4) { // frame_equalizer_vcvc_impl.cc:148-150
+            set_last_error("Missing constellation tag.");
+            return DTL_ERR_TAGS_MISSING;
+        }
+    if (!uploaded_) DTL_TRY(upload_tables());
+    DevBuf descs, stats, syms_scratch;
+    DTL_TRY(descs.ensure(size_t(n) * sizeof(FrameDesc)));
+    DTL_TRY(stats.ensure(size_t(n) * sizeof(FrameStat)));
+    if (!d_soft_syms) { DTL_TRY(syms_scratch.ensure(size_t(n) * capacity_ * sizeof(cf32))); d_soft_syms = syms_scratch.as<cf32>(); }
+    else DTL_HIP_CHECK(hipMemsetAsync(d_soft_syms, 0, size_t(n) * capacity_ * sizeof(cf32), st));
+    DTL_HIP_CHECK(hipMemcpyAsync(descs.p, descs_host, size_t(n) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+    DTL_TRY(launch_frame_eq_stage(tab_, d_frames, descs.as<FrameDesc>(), n, d_taps, stats.as<FrameStat>(), d_hard, d_soft,
+                                  d_soft_syms, st));
+    if (stats_host) DTL_HIP_CHECK(hipMemcpyAsync(stats_host, stats.p, size_t(n) * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    return DTL_OK;
+}
+
 // phase A (headers, demux walk) and phase B (payload kernels)
 int Receiver::stage_frames(Call& c)
 {
@@ -1279,58 +1430,15 @@ int Receiver::stage_blocks(Call& c)
         for (auto& d : decoders_) if (d) max_n = std::max(max_n, d->code.n);
         for (auto& m : cfg.mcs) max_bps = std::max(max_bps, m.cnst); // python/dtl/ofdm_adaptive.py:8
         asmb.rcv_cap = 2L * max_n * compute_tb_len(max_n, capacity_ * max_bps); // tb_decoder.cc:24-27
+        std::vector<CodeDims> dims(decoders_.size());
+        for (size_t i = 1; i < decoders_.size(); i++) if (decoders_[i]) dims[i] = { decoders_[i]->code.n, decoders_[i]->code.k };
         size_t fidx = 0;
         for (auto& fi : frames) {
             if (fi.payload_index < 0) continue;
             const FrameDesc& d = fdesc[fidx];
             const uint32_t base = llr_off[fidx];
             fidx++;
-            if (fi.payload_len == 0) continue; // empty frame never reaches the FEC decoder
-            const int bps = bits_per_symbol(d.cnst);
-            const long in_len = long(d.n_syms) * bps;
-            if (fi.fec <= 0 || fi.fec >= int(decoders_.size())) continue; // reference dereferences a null decoder here
-            const LdpcCode& code = decoders_[fi.fec]->code;
-            const int n_ = code.n, k_ = code.k, ncheck = n_ - k_;
-            const long frame_payload = 8L * fi.payload_len;           // fec_utils.cc:93
-            const long tb_offset = 8L * fi.tb_offset;                 // fec_decoder_impl.cc:147
-            const int frame_len = 8 * align_bits_to_bytes(capacity_ * bps); // :207
-            auto info_nk = [&](int& nn, int& kk) { const LdpcCode& c = decoders_[asmb.info_code]->code; nn = c.n; kk = c.k; };
-            if (fi.tb_no == asmb.tb_number) {
-                if (asmb.buf_idx + frame_payload > asmb.rcv_cap) { set_last_error("rcv buffer does not have enough capacity!"); return DTL_ERR_CAPACITY; }
-                asmb.append(base, 0, frame_payload, in_len);
-                asmb.buf_idx += frame_payload;
-                const int ncws = compute_tb_len(n_, frame_len);
-                if (asmb.rcv_size >= long(ncheck) * ncws + fi.tb_payload) {
-                    int nn, kk; info_nk(nn, kk);
-                    asmb.decode(ncws, nn, kk, fi.tb_no, fi.tb_payload);
-                    asmb.buf_idx = 0; asmb.clear();
-                }
-            } else if (asmb.rcv_size == 0 && tb_offset == frame_payload) {
-                asmb.have_info = true; asmb.info_tb_payload = fi.tb_payload; asmb.info_code = fi.fec;
-                asmb.tb_number = fi.tb_no; asmb.buf_idx = 0; asmb.clear();
-                asmb.append(base, 0, tb_offset, in_len);
-                asmb.decode(compute_tb_len(n_, frame_len), n_, k_, fi.tb_no, fi.tb_payload);
-                asmb.clear();
-            } else {
-                if (tb_offset > 0) asmb.append(base, 0, tb_offset, in_len);
-                if (asmb.rcv_size > 0 && asmb.have_info) {
-                    int nn, kk; info_nk(nn, kk);
-                    asmb.decode(compute_tb_len(nn, frame_len), nn, kk, asmb.tb_number, asmb.info_tb_payload);
-                }
-                asmb.have_info = true; asmb.info_tb_payload = fi.tb_payload; asmb.info_code = fi.fec;
-                asmb.tb_number = fi.tb_no; asmb.buf_idx = 0; asmb.clear();
-                int extra_bits = 0;
-                if (tb_offset % bps) extra_bits = int(bps - tb_offset % bps);
-                const long new_tb_offset = tb_offset ? tb_offset + extra_bits : 0;
-                asmb.append(base, new_tb_offset, frame_payload + extra_bits, in_len);
-                asmb.buf_idx += frame_payload - tb_offset;
-                const int tb_len = compute_tb_len(n_, frame_len);
-                const long tb_size = 8L * align_bits_to_bytes(tb_len * ncheck + fi.tb_payload);
-                if (frame_payload - tb_offset == tb_size) {
-                    asmb.decode(tb_len, n_, k_, fi.tb_no, fi.tb_payload);
-                    asmb.buf_idx = 0; asmb.clear();
-                }
-            }
+            DTL_TRY(tb_process_frame(asmb, fi, d.cnst, d.n_syms, base, capacity_, dims));
         }
     }
     if (asmb.overflow) { set_last_error("transport block spread over more than 4 stream segments"); return DTL_ERR_UNSUPPORTED; }
@@ -1551,6 +1659,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
         ~ResetOnExit() { if (armed) r->reset_stream(); }
     } reset_guard{ this, true };
     if (n < 0 || (!d_iq && n > 0)) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
+    if (cfg.has_fec && decoders_.size() < 2) { set_last_error("Misconfiguration: decoder not found!"); return DTL_ERR_INVALID_ARG; }
     frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
     n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
     for (double& s : stage_ms) s = 0.0;

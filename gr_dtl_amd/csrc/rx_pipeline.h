@@ -101,6 +101,14 @@ struct HostBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// one completed transport block of tb_gather_frames (mirrors dtl_tb_span of the C ABI)
+struct TbSpan {
+    int32_t tb_no, fec, tb_payload_bits, n_cw;
+    uint32_t cw_first, bits_off;
+};
+int tb_gather_frames(const std::vector<std::pair<int, int>>& code_nk, int capacity, int max_bps, const FrameInfo* frames,
+                     int64_t n_frames, std::vector<TbGather>& gathers, std::vector<TbSpan>& spans);
+
 class Receiver {
 public:
     RxConfig cfg;
@@ -130,6 +138,14 @@ public:
     double dbg_plateau_ms = 0;
     unsigned dbg_n_edges = 0;
     DevBuf d_payload, d_eq_hard, d_eq_soft, d_soft_syms, d_llr, d_taps, d_hdr_bits, d_metric, d_cw_bits, d_cw_nit;
+
+    // ---- single blocks of the graph on frequency-domain vectors (C ABI: dtl_chanest, dtl_header_decode,
+    // dtl_equalize_frames); stateless, usable next to process()
+    int chanest(const cf32* d_sync_syms, int n, int32_t* d_carr_off, cf32* d_taps, hipStream_t st);
+    int header_decode(const cf32* d_hdr_syms, const cf32* d_taps, const int32_t* d_carr_off, int n, HeaderRec* recs_host,
+                      uint8_t* d_hdr_bits, cf32* d_taps_out, hipStream_t st);
+    int equalize_frames(const cf32* d_frames, const cf32* d_taps, const FrameDesc* descs_host, int n, cf32* d_hard,
+                        cf32* d_soft, cf32* d_soft_syms, FrameStat* stats_host, hipStream_t st);
 
     int frame_capacity() const { return capacity_; }
     int frame_samples() const { return (2 + cfg.header_len() + cfg.frame_length) * (cfg.fft_len + cfg.cp_len); }

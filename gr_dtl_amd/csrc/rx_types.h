@@ -74,6 +74,18 @@ struct HeaderRec {
     int32_t pad;
 };
 
+// Extra arguments of the header kernel when it serves the per-block entry points dtl_chanest / dtl_header_decode
+// (frequency-domain vectors in, see header_kernel<true>); all null / zero for the receive path.
+struct HeaderStageIo {
+    const cf32* freq_in = nullptr;       // per block: n_rows x N vectors, shifted (DC at N/2)
+    int n_rows = 0, row0 = 0;            // rows supplied and the row of the (sync1, sync2, header...) stack the first one is
+    const cf32* taps_in = nullptr;       // non-null: channel estimate supplied (skip ofdm_chanest_vcvc)
+    const int32_t* carr_off_in = nullptr;
+    cf32* taps_raw_out = nullptr;        // the estimator's taps ("ofdm_sync_chan_taps")
+    int32_t* carr_off_out = nullptr;     // "ofdm_sync_carr_offset"
+    int do_header = 0;                   // run the header equaliser, slicer and parser
+};
+
 // One accepted frame handed to the payload kernel (phase B).
 struct FrameDesc {
     int64_t trigger;

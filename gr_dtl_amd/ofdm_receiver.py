@@ -92,6 +92,24 @@ def make_cfg_struct(cfg):
     return c, keep
 
 
+class HeaderFields(C.Structure):   # dtl_header_fields
+    _fields_ = [(n, C.c_int32) for n in ("crc_ok", "carr_offset", "payload_len", "frame_no", "cnst", "fb_cnst", "tb_no",
+                                         "fec_fb", "tb_offset", "fec", "tb_payload", "pad")]
+
+
+class FrameEqIn(C.Structure):      # dtl_frame_eq_in
+    _fields_ = [("cnst", C.c_int32), ("carr_offset", C.c_int32), ("n_payload_syms", C.c_int32), ("pad", C.c_int32)]
+
+
+class FrameEqOut(C.Structure):     # dtl_frame_eq_out
+    _fields_ = [("snr_db", C.c_double), ("noise_db", C.c_double), ("noise", C.c_double)]
+
+
+class TbSpan(C.Structure):         # dtl_tb_span
+    _fields_ = [("tb_no", C.c_int32), ("fec", C.c_int32), ("tb_payload_bits", C.c_int32), ("n_cw", C.c_int32),
+                ("cw_first", C.c_uint32), ("bits_off", C.c_uint32)]
+
+
 class FrameInfo(C.Structure):
     _fields_ = [("trigger", C.c_int64), ("header_ok", C.c_int32), ("carr_offset", C.c_int32),
                 ("payload_len", C.c_int32), ("frame_no", C.c_int32), ("cnst", C.c_int32), ("fb_cnst", C.c_int32),
@@ -238,6 +256,14 @@ class ofdm_receiver:
         L.dtl_rx_stream_position.argtypes = [C.c_void_p]
         L.dtl_rx_stream_position.restype = C.c_int64
         L.dtl_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dtl_chanest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dtl_header_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(HeaderFields),
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dtl_equalize_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameEqIn), C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.POINTER(FrameEqOut), C.c_void_p]
+        L.dtl_tb_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(TbSpan), C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]
         L._rx_declared = True
 
     def __del__(self):
@@ -251,6 +277,88 @@ class ofdm_receiver:
     @property
     def frame_samples(self):
         return (2 + self.header_len + self.frame_length) * (self.fft_len + self.cp_len)
+
+    # -- single blocks of the graph (frequency-domain vectors in; C ABI dtl_chanest / dtl_header_decode /
+    #    dtl_equalize_frames): what per-block shims of ofdm_chanest_vcvc, the header path and
+    #    ofdm_adaptive_frame_equalizer_vcvc call --------------------------------------------------------------
+    @staticmethod
+    def _dev(t, dtype, what):
+        if not (hasattr(t, "is_cuda") and t.is_cuda):
+            raise _lib.DtlError(_lib.ERR_NO_DEVICE, "%s needs a device tensor (no CPU fallback)" % what)
+        if t.dtype != dtype:
+            raise ValueError("%s: wrong dtype %s" % (what, t.dtype))
+        return t.contiguous()
+
+    def chanest(self, sync_syms):
+        """digital.ofdm_chanest_vcvc: sync_syms complex64 [n, 2, fft_len] (FFT output, shifted) ->
+        (carrier offsets int32 [n], taps complex64 [n, fft_len]) on the device."""
+        import torch
+        x = self._dev(sync_syms, torch.complex64, "chanest").view(-1, 2, self.fft_len)
+        n = x.shape[0]
+        off = torch.empty(n, dtype=torch.int32, device=x.device)
+        taps = torch.empty((n, self.fft_len), dtype=torch.complex64, device=x.device)
+        _lib.check(_lib.lib().dtl_chanest(self._h, x.data_ptr(), n, off.data_ptr(), taps.data_ptr(), _lib.current_stream_ptr()))
+        return off, taps
+
+    def header_decode(self, hdr_syms, taps, carr_offset, want_bits=False):
+        """Header equaliser + serializer + BPSK slicer + header parser: hdr_syms complex64 [n, header_len, fft_len],
+        taps / carrier offsets from chanest() -> (fields: numpy structured array [n], taps handed to the payload
+        equaliser [n, fft_len][, header bits uint8 [n, hdr_bits]])."""
+        import torch
+        x = self._dev(hdr_syms, torch.complex64, "header_decode").view(-1, self.header_len, self.fft_len)
+        n = x.shape[0]
+        taps = self._dev(taps, torch.complex64, "header_decode")
+        off = self._dev(carr_offset, torch.int32, "header_decode")
+        fields = (HeaderFields * max(n, 1))()
+        taps_out = torch.empty((n, self.fft_len), dtype=torch.complex64, device=x.device)
+        hdr_bits_len = self.header_len * len(self.occupied_carriers[0])
+        bits = torch.empty((n, hdr_bits_len), dtype=torch.uint8, device=x.device) if want_bits else None
+        _lib.check(_lib.lib().dtl_header_decode(self._h, x.data_ptr(), taps.data_ptr(), off.data_ptr(), n, fields,
+                                                bits.data_ptr() if want_bits else None, taps_out.data_ptr(),
+                                                _lib.current_stream_ptr()))
+        rec = np.frombuffer(bytes(fields), dtype=np.dtype([(k, "<i4") for k, _ in HeaderFields._fields_]))[:n].copy()
+        return (rec, taps_out, bits) if want_bits else (rec, taps_out)
+
+    def equalize_frames(self, frames, taps, cnst, carr_offset, n_payload_syms):
+        """gr::dtl::ofdm_adaptive_frame_equalizer_vcvc + ofdm_serializer_vcc: frames complex64 [n, frame_length,
+        fft_len]; per-frame constellation, carrier offset, payload symbol count (host sequences) ->
+        (eq_hard, eq_soft [n, L, fft_len], soft_syms [n, frame_capacity], stats numpy array (snr_db, noise_db, noise))."""
+        import torch
+        x = self._dev(frames, torch.complex64, "equalize_frames").view(-1, self.frame_length, self.fft_len)
+        n = x.shape[0]
+        taps = self._dev(taps, torch.complex64, "equalize_frames")
+        ins = (FrameEqIn * max(n, 1))()
+        for i in range(n):
+            ins[i] = FrameEqIn(int(cnst[i]), int(carr_offset[i]), int(n_payload_syms[i]), 0)
+        outs = (FrameEqOut * max(n, 1))()
+        hard = torch.empty_like(x)
+        soft = torch.empty_like(x)
+        syms = torch.empty((n, self.frame_capacity), dtype=torch.complex64, device=x.device)
+        _lib.check(_lib.lib().dtl_equalize_frames(self._h, x.data_ptr(), taps.data_ptr(), ins, n, hard.data_ptr(),
+                                                  soft.data_ptr(), syms.data_ptr(), outs, _lib.current_stream_ptr()))
+        stats = np.frombuffer(bytes(outs), dtype=np.dtype([("snr_db", "<f8"), ("noise_db", "<f8"), ("noise", "<f8")]))[:n].copy()
+        return hard, soft, syms, stats
+
+    def tb_gather(self, frames, code_nk, device, max_bps=4):
+        """gr::dtl::ofdm_adaptive_fec_decoder's transport-block reassembly as a gather table: frames = the `frames`
+        record array of a result (header fields + llr_offset), code_nk = [(n, k)] per FEC id 1.. ->
+        (dtl_cw_desc table: uint8 device tensor, spans: numpy structured array)."""
+        import torch
+        fr = np.ascontiguousarray(frames)
+        n = len(fr)
+        cn = np.array([c[0] for c in code_nk], dtype=np.int32)
+        ck = np.array([c[1] for c in code_nk], dtype=np.int32)
+        n_cw, n_sp = C.c_int64(0), C.c_int64(0)
+        cap_cw = max(16, int(sum(int(f["n_payload_syms"]) * 4 for f in fr) // min(cn) + 4 * n + 16))
+        cap_sp = 2 * n + 4
+        desc = torch.zeros(cap_cw * C.sizeof(_lib.CwDesc), dtype=torch.uint8, device=device)
+        spans = (TbSpan * cap_sp)()
+        _lib.check(_lib.lib().dtl_tb_gather(cn.ctypes.data, ck.ctypes.data, len(code_nk), self.frame_capacity, int(max_bps),
+                                            fr.ctypes.data, n, desc.data_ptr(), cap_cw, C.byref(n_cw), spans, cap_sp,
+                                            C.byref(n_sp), _lib.current_stream_ptr()))
+        rec = np.frombuffer(bytes(spans), dtype=np.dtype([("tb_no", "<i4"), ("fec", "<i4"), ("tb_payload_bits", "<i4"),
+                                                          ("n_cw", "<i4"), ("cw_first", "<u4"), ("bits_off", "<u4")]))
+        return desc[:int(n_cw.value) * C.sizeof(_lib.CwDesc)], rec[:int(n_sp.value)].copy()
 
     # -- batched work() -----------------------------------------------------------------------
     def work(self, iq, want=(), copy_outputs=True):

@@ -127,6 +127,10 @@ public:
     }
     int get_k() override { return dtl_ldpc_get_k(d_h); }
     int get_n() override { return dtl_ldpc_get_n(d_h); }
+    // the C-ABI handle, for the batched device entry points (dtl_ldpc_decode_batch / _gather)
+    const dtl_ldpc* handle() const { return d_h; }
+    // DTL_ARITH_GR_EXACT (default: the reference decoder's operations) / DTL_ARITH_FAST
+    void set_arith(int arith) { detail::check(dtl_ldpc_set_arith(d_h, arith)); }
 };
 
 inline std::vector<fec_enc::sptr> make_ldpc_encoders(const std::vector<std::string>& alist_fnames)

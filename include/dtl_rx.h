@@ -280,6 +280,70 @@ int dtl_soft_demap(const float* d_syms, int64_t n_syms, int32_t constellation, d
  * refout)); the value is returned to the host (the call synchronises `stream`) */
 int dtl_crc32(const uint8_t* d_bytes, int64_t len, uint32_t* crc_host, void* stream);
 
+/* ---- the blocks between the FFT and the soft demapper, on the frequency-domain vectors the reference's blocks
+ * exchange (fft_vcc output: fft_len complex per OFDM symbol, shifted, DC at fft_len/2).  The handle supplies the
+ * configuration (carrier maps, pilots, sync words, equaliser alpha ...); the calls are stateless. */
+/* digital.ofdm_chanest_vcvc(sync_word1, sync_word2, header_len) as wired at python/dtl/ofdm_receiver.py:102-103.
+ * d_sync_syms: n x 2 x fft_len (the two synchronisation symbols of n frames) -> per frame the integer carrier
+ * offset (tag "ofdm_sync_carr_offset") and fft_len initial channel taps (tag "ofdm_sync_chan_taps"), on the device */
+int dtl_chanest(dtl_rx* h, const float* d_sync_syms, int64_t n, int32_t* d_carr_offset, float* d_taps, void* stream);
+
+/* raw header fields of one frame + CRC-16 flag (the "header_data" message of packet_headerparser_b) */
+typedef struct dtl_header_fields {
+    int32_t crc_ok, carr_offset;
+    int32_t payload_len, frame_no, cnst, fb_cnst, tb_no, fec_fb, tb_offset, fec, tb_payload, pad;
+} dtl_header_fields;
+/* The header path behind the channel estimator (python/dtl/ofdm_receiver.py:104-150): ofdm_frame_equalizer_vcvc around
+ * gr::dtl::ofdm_adaptive_header_equalizer (lib/dtl/ofdm_adaptive_equalizer.cc:161-174), ofdm_serializer_vcc, BPSK
+ * constellation_decoder_cb, packet_headerparser_b with ofdm_adaptive_packet_header::header_parser
+ * (lib/dtl/ofdm_adaptive_packet_header.cc:231-312).  d_hdr_syms: n x header_len x fft_len; d_taps / d_carr_offset as
+ * dtl_chanest returns them.  fields_host[n]: the parsed fields as transmitted (the parser's "keep the previous
+ * constellation when the field is invalid" rule, :269-273, is sequential state and stays with the caller).
+ * Optional (may be NULL): d_hdr_bits n x header bits (1 per byte); d_taps_out n x fft_len taps handed on to the
+ * payload equaliser.  Synchronises `stream`. */
+int dtl_header_decode(dtl_rx* h, const float* d_hdr_syms, const float* d_taps, const int32_t* d_carr_offset, int64_t n,
+                      dtl_header_fields* fields_host, uint8_t* d_hdr_bits, float* d_taps_out, void* stream);
+
+/* what the frame equaliser block reads from tags (constellation, "ofdm_sync_carr_offset", packet length) */
+typedef struct dtl_frame_eq_in {
+    int32_t cnst, carr_offset, n_payload_syms, pad;
+} dtl_frame_eq_in;
+/* what it publishes per frame (estimated_snr_tag_key / noise_tag_key, lib/dtl/ofdm_adaptive_frame_equalizer_vcvc_impl.cc:195-216) */
+typedef struct dtl_frame_eq_out {
+    double snr_db, noise_db, noise;
+} dtl_frame_eq_out;
+/* gr::dtl::ofdm_adaptive_frame_equalizer_vcvc::make(equalizer, feedback_decision, cp_len, ...) -> work
+ * (include/gnuradio/dtl/ofdm_adaptive_frame_equalizer_vcvc.h:30-36, lib/dtl/ofdm_adaptive_frame_equalizer_vcvc_impl.cc:99-255)
+ * around ofdm_adaptive_payload_equalizer::equalize (lib/dtl/ofdm_adaptive_equalizer.cc:217-268), plus the
+ * ofdm_serializer_vcc behind it (python/dtl/ofdm_receiver.py:175-180), for n frames:
+ * d_frames: n x frame_length x fft_len; d_taps: n x fft_len (from dtl_header_decode); in_host[n].
+ * Outputs (each may be NULL): d_eq_hard / d_eq_soft n x frame_length x fft_len (out0 / out1 of the block: sliced and
+ * pre-slice symbols), d_soft_syms n x frame_capacity (serializer output, zero behind the frame's last symbol),
+ * out_host[n].  DTL_ERR_TAGS_MISSING ("Missing constellation tag.", :148-150) for a constellation outside 1..4.
+ * Synchronises `stream`. */
+int dtl_equalize_frames(dtl_rx* h, const float* d_frames, const float* d_taps, const dtl_frame_eq_in* in_host, int64_t n,
+                        float* d_eq_hard, float* d_eq_soft, float* d_soft_syms, dtl_frame_eq_out* out_host, void* stream);
+
+/* one completed transport block of dtl_tb_gather: codewords cw_first .. cw_first + n_cw - 1 of the descriptor table,
+ * decoded bits (1 per byte) at bits_off, tb_payload_bits of them (user bits + CRC-32) */
+typedef struct dtl_tb_span {
+    int32_t tb_no, fec, tb_payload_bits, n_cw;
+    uint32_t cw_first, bits_off;
+} dtl_tb_span;
+/* gr::dtl::ofdm_adaptive_fec_decoder::make(decoders, frame_capacity, max_bps, len_key) -> work
+ * (include/gnuradio/dtl/ofdm_adaptive_fec_decoder.h:27, lib/dtl/ofdm_adaptive_fec_decoder_impl.cc:80-217) ->
+ * tb_decoder::process_frame (lib/dtl/tb_decoder.cc:32-141) and the codeword split of tb_decoder::decode (:143-190),
+ * as index arithmetic: which soft bits of the stream every codeword takes.  frames_host: the frames of one
+ * self-contained run, in order (header fields, cnst, n_payload_syms, llr_offset = position of the frame's first soft
+ * bit in the soft-bit stream; frames with header_ok == 0 or llr_offset < 0 are skipped).  code_n / code_k: n_codes
+ * entries, FEC id i+1 -> entry i.  Writes one dtl_cw_desc per codeword to d_cw_desc (device, capacity cw_cap) for
+ * dtl_ldpc_decode_gather (codewords of different codes are NOT regrouped: use spans[].fec) and one dtl_tb_span per
+ * completed block to spans_host.  DTL_ERR_CAPACITY when a capacity is too small ("rcv buffer does not have enough
+ * capacity!" likewise), DTL_ERR_TAGS_MISSING for a frame without a valid constellation.  Synchronises `stream`. */
+int dtl_tb_gather(const int32_t* code_n, const int32_t* code_k, int32_t n_codes, int32_t frame_capacity, int32_t max_bps,
+                  const dtl_rx_frame_info* frames_host, int64_t n_frames, dtl_cw_desc* d_cw_desc, int64_t cw_cap,
+                  int64_t* n_cw, dtl_tb_span* spans_host, int64_t span_cap, int64_t* n_spans, void* stream);
+
 /* device-to-device copy on `stream` (lets a host binding snapshot result buffers it does not own) */
 int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);
 

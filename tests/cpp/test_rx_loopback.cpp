@@ -54,7 +54,7 @@ int main(int argc, char** argv)
     cfg.n_pilot_sets = 1; cfg.n_pilots = 4; cfg.pilot_carriers = pilots;
     cfg.n_pilot_sym_sets = 1; cfg.pilot_symbols = pilot_syms;
     cfg.sync_word1 = sw1.data(); cfg.sync_word2 = sw2.data();
-    cfg.sync_threshold = 0.95f; cfg.eq_alpha = 0.1f; cfg.use_sync_correct = 0;
+    cfg.sync_threshold = 0.95f; cfg.eq_alpha = 0.1f; cfg.use_sync_correct = 1;   // frame_detect_bb on: the receiver default
     cfg.max_iterations = 15; cfg.n_fec_codes = 1; cfg.alist_texts = texts; cfg.alist_lens = lens;
     cfg.n_mcs = 4; cfg.mcs_snr = mcs_snr; cfg.mcs_cnst = mcs_cnst; cfg.mcs_fec = mcs_fec;
     cfg.initial_mcs = 1; cfg.decision_th = 5; cfg.hysteresis = 1.0;
@@ -70,9 +70,8 @@ int main(int argc, char** argv)
     CHECK_HIP(hipMalloc(&d_user, size_t(n_user) + 1));
     CHECK_HIP(hipMemcpy(d_user, user.data(), size_t(n_user), hipMemcpyHostToDevice));
     dtl_tx_result t{};
-    // 32 idle samples after every frame (a paced transmitter): with frames back to back a trigger that is one
-    // sample early collides with the previous frame in the demux, as in the reference
-    CHECK_DTL(dtl_tx_process(tx, d_user, n_user, cnst, 1, 0, 0, /*gap=*/32, 0, nullptr, &t));
+    // frames back to back, as the reference's transmitter sends them (qa_ofdm_adaptive_txrx.py)
+    CHECK_DTL(dtl_tx_process(tx, d_user, n_user, cnst, 1, 0, 0, /*gap=*/0, 0, nullptr, &t));
 
     // 100 zeros in front (qa_ofdm_adaptive_txrx.py:82-83), one frame of zeros behind
     const int64_t n = 100 + t.n_samples + t.frame_samples;

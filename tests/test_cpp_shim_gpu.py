@@ -67,3 +67,22 @@ def test_cpp_rx_loopback(dtl, cuda, cnst, nbytes):
     out = subprocess.run([binary, ALIST_300, str(cnst), str(nbytes)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr + out.stdout
     assert out.stdout.startswith("OK") and ("bytes=%d" % nbytes) in out.stdout
+
+
+def test_cpp_blocks_shim_compiles(dtl):
+    """include/dtl_blocks.hpp (mirrors of ofdm_adaptive_frame_equalizer_vcvc::make / ofdm_adaptive_fec_decoder::make)
+    compiles and its factories run on a box without a GPU (the handles are created lazily on the host)."""
+    binary = _build("test_blocks_shim")
+    out = subprocess.run([binary, ALIST_300, "2", "100", "build-only"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK built"), out.stderr + out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cnst,nbytes", [(2, 6000), (4, 12000), (3, 5000)])
+def test_cpp_blocks_shim(dtl, cuda, cnst, nbytes):
+    """The block mirrors fed with the frequency-domain frames / soft bits of a TX -> RX run reproduce the whole
+    receiver's equalised symbols, SNR estimates, feedback decisions, transport blocks and bytes."""
+    binary = _build("test_blocks_shim")
+    out = subprocess.run([binary, ALIST_300, str(cnst), str(nbytes)], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert out.stdout.startswith("OK") and ("bytes=%d" % nbytes) in out.stdout

@@ -83,3 +83,121 @@ def test_stage_entry_points_refuse_host_memory(dtl):
                  lambda: stages.sync_sc(torch.zeros(100, dtype=torch.complex64), 64, 16)):
         with pytest.raises(dtl._lib.DtlError):
             call()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The blocks between the FFT and the soft demapper on frequency-domain vectors (dtl_chanest, dtl_header_decode,
+# dtl_equalize_frames) and the transport-block reassembly (dtl_tb_gather), each against the oracle's restatement of
+# the reference block it replaces.
+# ------------------------------------------------------------------------------------------------------------------
+def _frames_in_frequency_domain(oracle, ocfg, code, x):
+    """What fft_vcc hands the reference's header / payload paths for every frame the oracle's receiver finds:
+    [(record, (2 + h + L) x N shifted vectors)]."""
+    ref = oracle.rx_stream(ocfg, code, x, want=("frames", "trig", "angle", "taps", "eq_hard", "eq_soft", "soft_syms", "hdr_bits"))
+    mixed = oracle.cfo_mix(ocfg, x, ref["angle"])
+    N, P, cp = ocfg.fft_len, ocfg.fft_len + ocfg.cp_len, ocfg.cp_len
+    n_sym = 2 + ocfg.header_len + ocfg.frame_length
+    out = []
+    for i, f in enumerate(ref["frames"]):
+        t = f["trigger"]
+        if t + n_sym * P > x.size:
+            continue
+        rows = np.stack([oracle.fft_shifted(mixed[t + s * P + cp:t + s * P + cp + N]) for s in range(n_sym)])
+        out.append((i, f, rows.astype(np.complex64)))
+    return ref, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fft_len,cnst,esn0,cfo", [(64, 2, 14.0, 0.0), (64, 4, 24.0, 2.0), (256, 4, 23.0, 0.0), (64, 3, 20.0, -2.3)])
+def test_chanest_header_equalizer_blocks_match_oracle(oracle, dtl, cuda, fft_len, cnst, esn0, cfo):
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=8)
+    user, hdrs, x = make_stream(oracle, ocfg, code, cnst, 6000, esn0, seed=900 + fft_len + cnst)
+    if cfo:
+        n = np.arange(x.size, dtype=np.float64)
+        x = (x * np.exp(2j * np.pi * cfo * n / fft_len)).astype(np.complex64)
+    ref, frames = _frames_in_frequency_domain(oracle, ocfg, code, x)
+    assert len(frames) >= 10
+    rx = dtl.ofdm_receiver(pcfg)
+    h, L, N = ocfg.header_len, ocfg.frame_length, fft_len
+    rows = torch.from_numpy(np.stack([r for _, _, r in frames])).to(cuda)
+    # ---- ofdm_chanest_vcvc
+    off, taps = rx.chanest(rows[:, 0:2])
+    off_h, taps_h = off.cpu().numpy(), taps.cpu().numpy()
+    for j, (i, f, r) in enumerate(frames):
+        o_ref, t_ref = oracle.chanest(ocfg, r[0:2])
+        assert off_h[j] == o_ref == f["carr_offset"]
+        np.testing.assert_array_equal(_bits(taps_h[j]), _bits(t_ref))
+    if abs(cfo) >= 1.5:
+        assert (off_h != 0).all()
+    # ---- header equaliser + serializer + slicer + parser
+    fields, taps_out, bits = rx.header_decode(rows[:, 2:2 + h], taps, off, want_bits=True)
+    bits_h, taps_out_h = bits.cpu().numpy(), taps_out.cpu().numpy()
+    for j, (i, f, r) in enumerate(frames):
+        assert fields["crc_ok"][j] == f["header_ok"] and fields["carr_offset"][j] == f["carr_offset"]
+        np.testing.assert_array_equal(bits_h[j], ref["hdr_bits"][i])
+        if f["header_ok"]:
+            hd = f["hdr"]
+            for k in ("payload_len", "frame_no", "fb_cnst", "tb_no", "fec_fb", "tb_offset", "fec", "tb_payload"):
+                assert fields[k][j] == hd[k], (k, j)
+            np.testing.assert_array_equal(_bits(taps_out_h[j]), _bits(ref["taps"][i]))
+    # ---- payload frame equaliser + serializer
+    ok = [j for j, (i, f, r) in enumerate(frames) if f["header_ok"]]
+    assert len(ok) >= 8
+    sel = torch.tensor(ok, device=cuda)
+    cn = [frames[j][1]["hdr"]["cnst"] for j in ok]
+    of = [frames[j][1]["carr_offset"] for j in ok]
+    ns = [frames[j][1]["n_payload_syms"] for j in ok]
+    hard, soft, syms, stats = rx.equalize_frames(rows[sel][:, 2 + h:], taps_out[sel], cn, of, ns)
+    hard, soft, syms = hard.cpu().numpy(), soft.cpu().numpy(), syms.cpu().numpy()
+    for q, j in enumerate(ok):
+        i, f, r = frames[j]
+        np.testing.assert_array_equal(hard[q], ref["eq_hard"][i])
+        same = _bits(soft[q]) == _bits(ref["eq_soft"][i])
+        assert same.mean() > 0.999
+        np.testing.assert_allclose(soft[q], ref["eq_soft"][i], rtol=1e-5, atol=2e-6)
+        nsym = min(f["n_payload_syms"], ocfg.frame_capacity) if f["hdr"]["payload_len"] else 0
+        np.testing.assert_allclose(syms[q][:nsym], ref["soft_syms"][i][:nsym], rtol=1e-5, atol=2e-6)
+        assert abs(stats["snr_db"][q] - f["snr_db"]) <= 1e-6 * abs(f["snr_db"]) + 1e-6
+        assert abs(stats["noise"][q] - f["noise_lin"]) <= 1e-5 * abs(f["noise_lin"])
+    # a frame without a valid constellation is the reference's "Missing constellation tag." exception
+    with pytest.raises(dtl._lib.DtlError) as e:
+        rx.equalize_frames(rows[sel][:1, 2 + h:], taps_out[sel][:1], [0], [0], [10])
+    assert e.value.code == dtl._lib.ERR_TAGS_MISSING
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cnst,esn0,frame_length", [(2, 13.0, 20), (4, 23.0, 20), (1, 20.0, 3), (3, 21.0, 5)])
+def test_tb_gather_matches_receiver_and_oracle(oracle, dtl, cuda, cnst, esn0, frame_length):
+    """dtl_tb_gather + dtl_ldpc_decode_gather on the soft bits of a receiver run reproduce the run's own transport
+    blocks (= the oracle's tb_decoder, test_rx_gpu): block numbers, codeword counts, CRC flags, payload bytes.
+    frame_length 3 / 5: blocks spread over several short frames (more than four pieces before merging)."""
+    import ctypes as C
+    import torch
+    import zlib
+    from conftest import ALIST_300
+    pcfg, ocfg, code = make_pair(oracle, dtl, frame_length=frame_length)
+    user, hdrs, x = make_stream(oracle, ocfg, code, cnst, 5000, esn0, seed=40 + cnst)
+    rx = dtl.ofdm_receiver(pcfg)
+    res = rx.work(torch.from_numpy(x).to(cuda), want=("llr",))
+    ref = oracle.rx_stream(ocfg, code, x)
+    assert [t["tb_no"] for t in res.tbs] == [t["tb_no"] for t in ref["tbs"]] and len(res.tbs) >= 5
+    desc, spans = rx.tb_gather(res.frames, [(code.n, code.k)], cuda)
+    assert [int(s) for s in spans["tb_no"]] == [int(t["tb_no"]) for t in res.tbs]
+    assert [int(s) for s in spans["tb_payload_bits"]] == [int(t["tb_payload"]) for t in res.tbs]
+    n_cw = desc.numel() // C.sizeof(dtl._lib.CwDesc)
+    assert n_cw == int(spans["n_cw"].sum()) == res.n_codewords
+    dec = dtl.ldpc_dec(ALIST_300)
+    bits = torch.zeros(int(spans["bits_off"][-1]) + int(spans["tb_payload_bits"][-1]) + 64, dtype=torch.uint8, device=cuda)
+    nit = torch.zeros(n_cw, dtype=torch.int32, device=cuda)
+    dec.decode_gather(res.llr, desc, bits, nit)
+    bits = bits.cpu().numpy()
+    payload = res.payload.cpu().numpy()
+    for sp, t in zip(spans, res.tbs):
+        b = bits[sp["bits_off"]:sp["bits_off"] + sp["tb_payload_bits"]]
+        by = np.packbits(b.reshape(-1, 8)[:, ::-1], axis=1).ravel()
+        crc_ok = int(by.size >= 4 and (zlib.crc32(by[:-4].tobytes()) & 0xFFFFFFFF) == int.from_bytes(by[-4:].tobytes(), "little"))
+        assert crc_ok == int(t["crc_ok"])
+        if crc_ok:
+            np.testing.assert_array_equal(by[:-4], payload[t["out_offset"]:t["out_offset"] + t["user_bits"] // 8])
+    assert sum(int(t["crc_ok"]) for t in res.tbs) >= 3
