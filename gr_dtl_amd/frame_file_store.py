@@ -89,43 +89,80 @@ def store_rx_frames(store, rx_result):
         store.store(n & 0xFFF, int(t["tb_no"]), payload[off:off + n])
 
 
-def ber_report(tx_fname, rx_fname):
+def _records(blob, start=0):
+    """(long_count, payload_len, payload_offset) of every record from byte `start` on"""
+    out, pos = [], start
+    while pos + _REC.size <= len(blob):
+        ln, n = _REC.unpack_from(blob, pos)
+        pos += _REC.size
+        out.append((n, ln, pos))
+        pos += ln
+    return out
+
+
+def ber_report(tx_fname, rx_fname, tool_compat=True):
     """The figures tools/ber.py prints, as a dict: frames/bits sent and received, missed frames, frames
     without / with bit errors, BER over everything sent (missing frames count as all-wrong), BER over the
-    received frames, FER."""
-    tx = read_frames(tx_fname)
-    rx = read_frames(rx_fname)
-    tx_index = {n: i for i, (n, _) in enumerate(tx)}
-    # both dumps are compared from the first RX frame that the TX dump knows
-    start_rx = next((i for i, (n, _) in enumerate(rx) if n in tx_index), None)
+    received frames, FER.
+
+    tool_compat=True (default) reproduces the reference's tool exactly, including where it reads the bytes it
+    compares: tools/ber.py:104 adds the 12-byte record header to offsets that already point BEHIND the header
+    (`headers()` yields f.tell() after the header, :15), so for every matched frame it compares bytes 12 .. 12+len
+    behind the payload start in both files -- the payload without its first 12 bytes plus the 12 header bytes of the
+    NEXT record (shorter at the end of a file).  A frame followed by different neighbours in the two dumps (a lost
+    frame) is therefore counted as a frame in error.  Pinned on the tool's own output, tests/golden/ber_tool/.
+    tool_compat=False compares payload with payload (what the tool means to do)."""
+    with open(tx_fname, "rb") as f:
+        tx_blob = f.read()
+    with open(rx_fname, "rb") as f:
+        rx_blob = f.read()
+    empty = dict(frames_sent=0, frames_received=0, bits_sent=0, bits_received=0, missed=0, crc_ok=0, crc_fail=0,
+                 ber_overall=None, ber_detected=None, fer=None, mismatch_length=0, missing_tx=0)
+    # both dumps are read from the first RX record whose number the TX dump knows (:51-62)
+    tx_all = _records(tx_blob)
+    start_rx = start_tx = None
+    for rx_n, _, rx_off in _records(rx_blob):
+        hit = next((t_off for t_n, _, t_off in tx_all if t_n == rx_n), None)
+        if hit is not None:
+            start_rx, start_tx = rx_off - _REC.size, hit - _REC.size
+            break
     if start_rx is None:
-        return dict(frames_sent=0, frames_received=0, bits_sent=0, bits_received=0, missed=0, crc_ok=0, crc_fail=0,
-                    ber_overall=None, ber_detected=None, fer=None, mismatch_length=0, missing_tx=0)
-    tx = tx[tx_index[rx[start_rx][0]]:]
-    rx = rx[start_rx:]
-    tx_map = {n: p for n, p in tx}
-    frames_sent = len(tx)
-    bits_sent = sum(len(p) for _, p in tx) * 8
-    matched = {}
+        return empty
+    tx_headers, frames_sent, bits_sent = {}, 0, 0
+    for n, ln, off in _records(tx_blob, start_tx):                      # :84-87 (a repeated number: the last wins)
+        tx_headers[n] = (off, ln)
+        bits_sent += ln * 8
+        frames_sent += 1
+    offsets, rx_headers = [], {}
     mismatch_length = missing_tx = 0
-    for n, p in rx:
-        if n not in tx_map:
+    for n, ln, off in _records(rx_blob, start_rx):                      # :90-102
+        if n not in tx_headers:
             missing_tx += 1
-        elif len(tx_map[n]) != len(p):
+            continue
+        tx_off, tx_len = tx_headers[n]
+        if tx_len != ln:
             mismatch_length += 1
-        else:
-            matched[n] = p
-    missed = [n for n, _ in tx if n not in matched]
-    missing_bits = sum(len(tx_map[n]) for n in missed) * 8
-    errors = bits_received = frame_errors = 0
-    for n, p in matched.items():
-        e = sum(bin(a ^ b).count("1") for a, b in zip(tx_map[n], p))
+            continue
+        offsets.append((off, tx_off, ln))
+        rx_headers[n] = (off, ln)
+    missed = missing_bits = 0
+    for n, ln, _ in _records(tx_blob, start_tx):                        # :104-107
+        if n not in rx_headers:
+            missed += 1
+            missing_bits += ln * 8
+    shift = _REC.size if tool_compat else 0
+    errors = bits_received = frames_received = frame_errors = 0
+    for rx_off, tx_off, ln in offsets:                                  # :113-127
+        a = tx_blob[tx_off + shift:tx_off + shift + ln]
+        b = rx_blob[rx_off + shift:rx_off + shift + ln]
+        e = sum(bin(x ^ y).count("1") for x, y in zip(a, b))
+        bits_received += ln * 8
+        frames_received += 1
         errors += e
-        bits_received += len(p) * 8
         frame_errors += e > 0
-    return dict(frames_sent=frames_sent, frames_received=len(matched), bits_sent=bits_sent, bits_received=bits_received,
-                missed=len(missed), crc_ok=len(matched) - frame_errors, crc_fail=frame_errors,
+    return dict(frames_sent=frames_sent, frames_received=frames_received, bits_sent=bits_sent, bits_received=bits_received,
+                missed=missed, crc_ok=frames_received - frame_errors, crc_fail=frame_errors,
                 ber_overall=(errors + missing_bits) / bits_sent if bits_sent else None,
                 ber_detected=errors / bits_received if bits_received else None,
-                fer=(frame_errors + len(missed)) / frames_sent if frames_sent else None,
+                fer=(frame_errors + missed) / frames_sent if frames_sent else None,
                 mismatch_length=mismatch_length, missing_tx=missing_tx)

@@ -71,7 +71,7 @@ def test_no_fec_frame_dumps_and_ber_report(oracle, dtl, cuda, tmp_path):
         dtl.store_tx_frames(st, user, per)
     with dtl.frame_file_store(rxf) as st:
         dtl.store_rx_frames(st, res)
-    rep = dtl.ber_report(txf, rxf)
+    rep = dtl.ber_report(txf, rxf, tool_compat=False)   # payload against payload (the tool itself reads 12 bytes late)
     assert rep["frames_sent"] >= 55 and rep["frames_received"] >= 40
     assert rep["mismatch_length"] == 0 and rep["missing_tx"] == 0
     # frames without bit errors are exactly the frames whose CRC-32 passed

@@ -47,7 +47,7 @@ def test_ber_report_counts(dtl, tmp_path):
                 q[0] ^= 0x07                               # 3 bit errors
             rx.store(len(q), i, bytes(q))
     # RX's own long count starts at its first frame number: 2 (0 -> 2 is an increment of 2)
-    r = dtl.ber_report(txf, rxf)
+    r = dtl.ber_report(txf, rxf, tool_compat=False)
     assert r["frames_sent"] == 8 and r["frames_received"] == 7 and r["missed"] == 1
     assert r["crc_ok"] == 6 and r["crc_fail"] == 1
     assert r["bits_sent"] == 8 * 20 * 8 and r["bits_received"] == 7 * 20 * 8
@@ -84,3 +84,46 @@ def test_monitor_probe_counters(dtl):
     # counters continue over the next call (a continued stream)
     dec2 = p.dec_msgs(r)
     assert dec2[-1]["crc_ok_count"] == 4 and dec2[-1]["crc_fail_count"] == 2
+
+
+# ---- pinned on the reference's own tool: tests/golden/ber_tool/ holds dumps written by frame_file_store and what
+# /root/reference/tools/ber.py printed for them in the build container (tests/golden/make_ber_fixtures.py)
+def _parse_ber_py(text):
+    import re
+    out = {}
+    pats = {"mismatch_length": r"mismatch length=(\d+)", "missing_tx": r"missing txs=(\d+)", "matched": r"Matched frames:\s+(\d+)",
+            "frames_sent": r"Sent: frames=(\d+)", "bits_sent": r"Sent: frames=\d+, bits=(\d+)",
+            "frames_received": r"Received: frames=(\d+)", "bits_received": r"Received: frames=\d+, bits=(\d+)",
+            "missed": r"missed=(\d+)", "crc_ok": r"crc_ok=(\d+)", "crc_fail": r"crc_fail=(\d+)",
+            "ber_overall": r"BER \(overall\): (\S+)", "ber_detected": r"BER \(detected frames\): (\S+)", "fer": r"FER: (\S+)"}
+    for k, p in pats.items():
+        m = re.search(p, text)
+        assert m, k
+        out[k] = float(m.group(1)) if k in ("ber_overall", "ber_detected", "fer") else int(m.group(1))
+    return out
+
+
+def test_ber_report_equals_the_reference_tool(dtl, tmp_path):
+    import importlib.util
+    import os
+    from conftest import GOLDEN
+    spec = importlib.util.spec_from_file_location("make_ber_fixtures", os.path.join(GOLDEN, "make_ber_fixtures.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    cases = gen.scenarios()
+    assert len(cases) >= 4
+    for name, (tx, rx) in cases.items():
+        base = os.path.join(GOLDEN, "ber_tool", name)
+        # (a) the writer reproduces the committed dumps byte for byte
+        for side, recs in (("tx", tx), ("rx", rx)):
+            fn = str(tmp_path / (name + "." + side + ".bin"))
+            gen.write_dump(fn, recs)
+            assert open(fn, "rb").read() == open(base + "." + side + ".bin", "rb").read(), (name, side)
+        # (b) ber_report gives the figures the reference's tool printed
+        want = _parse_ber_py(open(base + ".ber_py.txt").read())
+        got = dtl.ber_report(base + ".tx.bin", base + ".rx.bin")
+        for k in ("frames_sent", "bits_sent", "frames_received", "bits_received", "missed", "crc_ok", "crc_fail",
+                  "mismatch_length", "missing_tx"):
+            assert got[k] == want[k], (name, k, got[k], want[k])
+        for k in ("ber_overall", "ber_detected", "fer"):
+            assert got[k] == want[k], (name, k, got[k], want[k])
