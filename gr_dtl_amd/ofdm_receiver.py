@@ -450,21 +450,128 @@ class ofdm_receiver:
         return out
 
 
+class rx_ports:
+    """The seven output streams of the reference's `ofdm_adaptive_rx` hier block for one buffer of input samples
+    (python/dtl/ofdm_adaptive_rx.py:42-59, grc/dtl_ofdm_adaptive_rx.block.yml:22-53), as device tensors, plus the
+    `monitor` message port as a list of dicts.  `out[i]` is port i."""
+
+    def __init__(self, out, monitor, result):
+        self.out = out
+        self.monitor = monitor
+        self.result = result          # the underlying rx_result (record arrays)
+
+    def __getitem__(self, i):
+        return self.out[i]
+
+    def __len__(self):
+        return len(self.out)
+
+
 class ofdm_adaptive_rx:
-    """python/dtl/ofdm_adaptive_rx.py:32-59 (the feedback side-channel transmitter of
-    _setup_feedback_tx is outside the accelerated path)."""
+    """Adaptive OFDM Simple modem (RX): python/dtl/ofdm_adaptive_rx.py:32-59.  One complex input stream; seven
+    output streams + the `monitor` message port:
+
+      0  byte     decoded user bytes (FEC: bytes of the CRC-ok transport blocks; no FEC: every packed frame)
+      1  complex  feedback transmitter samples -- the side-channel modem of _setup_feedback_tx (:62-113) is outside
+                  the accelerated path: always empty here; the decisions it would send are in monitor / result.frames
+      2  byte     trigger stream after ofdm_adaptive_frame_detect_bb: one byte per input sample, 1 at a trigger
+      3  byte     trigger stream of ofdm_sync_sc_cfb (raw)
+      4  complex x fft_len  payload equaliser out0: equalised and sliced symbols, frame_length vectors per frame
+      5  complex  payload equaliser out1 (pre-slice symbols), the vectors flattened to a stream of complex items
+                  as the hier block's port declares it (ofdm_receiver.py:18-20,244)
+      6  float    fine frequency offset of ofdm_sync_sc_cfb: arg(P) sampled at each raw trigger and held
+
+    work(iq) = one self-contained buffer; feed(iq, final) continues a stream (ofdm_receiver.feed)."""
 
     @classmethod
     def from_parameters(cls, config_dict=None, **kwargs):
         cfg = make_rx_config(config_dict)
-        for key, val in kwargs.items():
-            if hasattr(cfg, key):
-                setattr(cfg, key, val)
+        cfg.__dict__.update(kwargs)          # as the reference does (:38); unknown keys become attributes
         return cls(cfg)
 
     def __init__(self, config):
+        from .monitor import monitor_probe
         self.config = config
         self.direct_rx = ofdm_receiver(config)
+        self._probe = monitor_probe()
+        self._raw, self._ang, self._fixed = [], [], []   # triggers not yet fully emitted on ports 2 / 3 / 6 (absolute)
+        self._emitted = 0                                # ports 2 / 3 / 6 have been produced up to this sample
+
+    def _ports(self, dev, res, lo, hi):
+        """Port streams for the sample range [lo, hi) (absolute indices) from the triggers known so far."""
+        import torch
+        n = max(int(hi - lo), 0)
+
+        def trigger_stream(pos):
+            t = torch.zeros(n, dtype=torch.uint8, device=dev)
+            p = np.asarray(pos, dtype=np.int64) - lo
+            p = p[(p >= 0) & (p < n)]
+            if p.size:
+                t[torch.as_tensor(p, device=dev)] = 1
+            return t
+        raw = np.asarray(self._raw, dtype=np.int64)
+        ang = np.asarray(self._ang, dtype=np.float32)
+        # sample_and_hold_ff: the value at a trigger is held up to the next one; zero before the first
+        freq = torch.zeros(n, dtype=torch.float32, device=dev)
+        if n and raw.size:
+            sel = raw < hi
+            pos = torch.as_tensor(raw[sel] - lo, device=dev)
+            val = torch.as_tensor(ang[sel], device=dev)
+            if pos.numel():
+                idx = torch.bucketize(torch.arange(n, device=dev), pos, right=True) - 1
+                freq = torch.where(idx >= 0, val[idx.clamp(min=0)], freq)
+        N = self.direct_rx.fft_len
+        hard = res.eq_hard.reshape(-1, N) if res.eq_hard is not None else torch.zeros((0, N), dtype=torch.complex64, device=dev)
+        soft = res.eq_soft.reshape(-1) if res.eq_soft is not None else torch.zeros(0, dtype=torch.complex64, device=dev)
+        out = [res.payload, torch.zeros(0, dtype=torch.complex64, device=dev), trigger_stream(self._fixed),
+               trigger_stream(self._raw), hard, soft, freq]
+        rx = self.direct_rx
+        code = None
+        if rx.fec:
+            from .fec import ldpc_dec
+            if not hasattr(self, "_code_nk"):
+                d = ldpc_dec(rx.codes_alist[0])
+                self._code_nk = (d.get_n(), d.get_k())
+            code = self._code_nk
+        monitor = self._probe.eq_msgs(res) + (self._probe.dec_msgs(res, *code) if code else self._probe.dec_msgs(res))
+        return rx_ports(out, monitor, res)
+
+    def _remember(self, res, keep_from):
+        """Triggers of this call joined to the ones still needed: everything at or behind `keep_from`, plus the last
+        raw trigger in front of it (its angle is the held value there)."""
+        raw = list(self._raw) + [int(v) for v in res.raw_triggers]
+        ang = list(self._ang) + [float(v) for v in res.sc_freq]
+        first = 0
+        for i, p in enumerate(raw):
+            if p < keep_from:
+                first = i
+        self._raw, self._ang = raw[first:], ang[first:]
+        self._fixed = [p for p in list(self._fixed) + [int(v) for v in res.fixed_triggers] if p >= keep_from]
 
     def work(self, iq, want=()):
-        return self.direct_rx.work(iq, want=want)
+        """One self-contained buffer of samples -> rx_ports."""
+        res = self.direct_rx.work(iq, want=tuple(set(want) | {"eq_hard", "eq_soft"}))
+        self._raw, self._ang, self._fixed, self._emitted = [], [], [], 0
+        self._remember(res, 0)
+        ports = self._ports(iq.device, res, 0, iq.numel())
+        self._raw, self._ang, self._fixed = [], [], []
+        return ports
+
+    def feed(self, iq, final=False, want=()):
+        """Streaming form: consecutive buffers of one sample stream (what the scheduler hands the hier block).  The
+        per-sample ports (2, 3, 6) trail the input by one frame, like the reference graph's own latency: a trigger is
+        known only when its plateau has ended and frame_detect_bb has seen the following samples.  final=True flushes."""
+        end = self.direct_rx.stream_position + iq.numel()
+        res = self.direct_rx.feed(iq, want=tuple(set(want) | {"eq_hard", "eq_soft"}), final=final)
+        hi = end if final else max(self._emitted, end - self.direct_rx.frame_samples)
+        self._remember(res, self._emitted)
+        ports = self._ports(iq.device, res, self._emitted, hi)
+        self._emitted = hi
+        self._remember(_NoTriggers, hi)
+        if final:
+            self._raw, self._ang, self._fixed, self._emitted = [], [], [], 0
+        return ports
+
+
+class _NoTriggers:
+    raw_triggers = fixed_triggers = sc_freq = ()
