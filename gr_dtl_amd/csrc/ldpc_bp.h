@@ -47,8 +47,11 @@ public:
     ~LdpcDecoder();
     int upload();  // build device tables
     // llr: device float stream; desc==nullptr => codeword i at llr + i*n, all k bits, out at i*k
+    // packed: d_bits is a ZEROED, 8-byte aligned buffer that receives 1 bit per decoded bit (LSB first) at bit
+    // position out_off instead of one byte per bit
     int decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, uint8_t* d_bits, int32_t* d_nit,
-               hipStream_t stream) const;
+               hipStream_t stream, bool packed = false) const;
+    bool packed_output_ok() const { return np_ok_; }
     size_t lds_bytes() const;
     bool uploaded() const { return blob_ != nullptr; }
 

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                                                                      int max_it, float sigma,
                                                                      uint8_t* __restrict__ out_bits,
                                                                      int32_t* __restrict__ out_nit,
-                                                                     unsigned int* __restrict__ queue, int chunk)
+                                                                     unsigned int* __restrict__ queue, int chunk, int packed)
 {
     static_assert(MAXC <= 4, "a variable's slot indices are read as one 64-bit word");
     extern __shared__ unsigned char np_smem[];
@@ -545,7 +545,23 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             if (FAST || __ballot(wild) != 0ull) iterate(std::false_type{});
             else iterate(std::true_type{});
         }
-        for (int i = lane; i < k_used; i += kWave) out_bits[size_t(out_off) + i] = est[sys_src[i]];
+        if (packed) {
+            // 1 bit per bit, LSB first (what fec_pack / the CRC check want): 64 decisions per ballot, OR-ed into the
+            // zeroed output words at bit position out_off (codewords of a block are not byte aligned in general)
+            unsigned long long* words = reinterpret_cast<unsigned long long*>(out_bits);
+            for (int i0 = 0; i0 < k_used; i0 += kWave) {
+                const int i = i0 + lane;
+                const unsigned long long w = __ballot(i < k_used && est[sys_src[i < k_used ? i : 0]] != 0);
+                if (lane == 0 && w) {
+                    const unsigned long long pos = (unsigned long long)(out_off) + (unsigned long long)(i0);
+                    const unsigned sh = unsigned(pos & 63ull);
+                    atomicOr(&words[pos >> 6], w << sh);
+                    if (sh && (w >> (64 - sh))) atomicOr(&words[(pos >> 6) + 1], w >> (64 - sh));
+                }
+            }
+        } else {
+            for (int i = lane; i < k_used; i += kWave) out_bits[size_t(out_off) + i] = est[sys_src[i]];
+        }
         if (lane == 0) out_nit[cw] = nit;
         wave_sync(); // the wave's LDS slice is reused by its next codeword
 #pragma unroll
@@ -671,7 +687,7 @@ int LdpcDecoder::upload()
 }
 
 int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, uint8_t* d_bits,
-                        int32_t* d_nit, hipStream_t stream) const
+                        int32_t* d_nit, hipStream_t stream, bool packed) const
 {
     if (!blob_) { set_last_error("ldpc: tables not uploaded"); return DTL_ERR_INVALID_ARG; }
     if (ncw == 0) return DTL_OK;
@@ -698,10 +714,11 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
         unsigned int* queue = np_queue_ + (np_launch_.fetch_add(1, std::memory_order_relaxed) % kNpQueueRing);
         DTL_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned int), stream));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_chk_var_, np_var_edge_, np_chk_deg_, np_perm_,
-                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk);
+                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk, packed ? 1 : 0);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
     }
+    if (packed) { set_last_error("ldpc: packed output is implemented by the node-parallel kernel only"); return DTL_ERR_UNSUPPORTED; }
     if (arith == DTL_ARITH_FAST) {
         set_last_error("ldpc: the fast arithmetic is implemented by the node-parallel kernel only (row weight <= 8, column weight <= 4, n <= 512)");
         return DTL_ERR_UNSUPPORTED;

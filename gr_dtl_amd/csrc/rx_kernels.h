@@ -26,7 +26,7 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
                    const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms,
                    uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st);
 int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
-                    int stride, TbResult* res, int32_t* len, hipStream_t st);
+                    int stride, TbResult* res, int32_t* len, hipStream_t st, bool packed = false);
 int launch_expand_cw(const TbGather* tbs, int n_tbs, CwDesc* out, hipStream_t st);
 int launch_nofec_lengths(const int32_t* info, int n, int32_t* len, hipStream_t st);
 int launch_compact(const uint8_t* staging, int stride, const int32_t* len, int n, uint32_t* offs,

@@ -1120,6 +1120,9 @@ __device__ __forceinline__ uint32_t crc32_shift(uint32_t v, unsigned k, const ui
     return v;
 }
 
+// PACKED: `bits` holds the decoder's packed output (1 bit per bit, LSB first; block at bit offset bits_off, a multiple
+// of 8) -- the block's bytes are read as they are; otherwise one byte per bit, repacked here.
+template <bool PACKED>
 __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__ tbs, int n_tbs,
                                                      const uint8_t* __restrict__ bits,
                                                      const int32_t* __restrict__ nit,
@@ -1153,6 +1156,19 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
     const TbDesc d = tbs[tb];
     uint8_t* bytes = staging + size_t(tb) * stride;
     const int n_bytes = int(d.n_bits / 8);
+    if constexpr (PACKED) {
+        const uint8_t* src = bits + size_t(d.bits_off / 8);
+        for (int b0 = lane; b0 < n_bytes; b0 += 64 * 4) {
+            uint8_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = src[min(b0 + 64 * j, n_bytes - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int b = b0 + 64 * j;
+                if (b < n_bytes) { bytes_l[b] = v[j]; bytes[b] = v[j]; }
+            }
+        }
+    } else
     for (int b0 = lane; b0 < n_bytes; b0 += 64 * 4) {
         unsigned long long w[4];
 #pragma unroll
@@ -1529,7 +1545,7 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
 }
 
 int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
-                    int stride, TbResult* res, int32_t* len, hipStream_t st)
+                    int stride, TbResult* res, int32_t* len, hipStream_t st, bool packed)
 {
     if (n_tbs <= 0) return DTL_OK;
     const size_t lds = (256 + 16 * 32) * 4 + size_t((stride + 15) & ~15);
@@ -1560,7 +1576,8 @@ int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int
         d_zmat = p; zmat_dev = dev;
     }
     if ((stride / 1) >= (1 << 16)) { set_last_error("tb_check: transport block above 64 KiB"); return DTL_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(tb_check_kernel, dim3(n_tbs), dim3(64), lds, st, tbs, n_tbs, bits, nit, staging, stride, res, d_zmat);
+    if (packed) hipLaunchKernelGGL(tb_check_kernel<true>, dim3(n_tbs), dim3(64), lds, st, tbs, n_tbs, bits, nit, staging, stride, res, d_zmat);
+    else hipLaunchKernelGGL(tb_check_kernel<false>, dim3(n_tbs), dim3(64), lds, st, tbs, n_tbs, bits, nit, staging, stride, res, d_zmat);
     hipLaunchKernelGGL(tb_lengths_kernel, dim3((n_tbs + 255) / 256), dim3(256), 0, st, res, n_tbs, len);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;

@@ -1447,6 +1447,7 @@ int Receiver::stage_blocks(Call& c)
     std::vector<TbGather> gathers(n_tbs);
     std::vector<TbDesc> tb_desc(n_tbs);
     std::vector<std::pair<int, std::pair<size_t, size_t>>> code_ranges; // code -> [first, count)
+    uint32_t bits_total = 0;
     size_t n_cw_total = 0;
     uint64_t max_out_bytes = 0;
     int stride = 16;
@@ -1475,6 +1476,7 @@ int Receiver::stage_blocks(Call& c)
         n_codewords = int64_t(n_cw_total);
         stride = (stride + 15) & ~15;
         DTL_TRY(d_cw_bits.ensure(size_t(bits_base) + 4096));
+        bits_total = bits_base;
     }
     stage_ms[3] = now_ms() - t0; t0 = now_ms();
 
@@ -1495,12 +1497,17 @@ int Receiver::stage_blocks(Call& c)
             DTL_TRY(upload_vec(h_tbdesc_, d_tbdesc_, tb_desc, st));
             DTL_TRY(launch_expand_cw(d_tbgather_.as<TbGather>(), n_tbs, d_cwdesc_.as<CwDesc>(), st));
             if (ev_[2]) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
+            // the decoder packs its decisions (1 bit per bit) when every code in use runs on the node-parallel kernel:
+            // an eighth of the bytes out and back in; the buffer is zeroed first (the kernel ORs words in)
+            bool packed = true;
+            for (auto& cr : code_ranges) packed = packed && decoders_[cr.first]->packed_output_ok();
+            if (packed) DTL_HIP_CHECK(hipMemsetAsync(d_cw_bits.p, 0, (size_t(bits_total) / 8 + 64 + 7) & ~size_t(7), st));
             for (auto& cr : code_ranges)
                 DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
-                                                    d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st));
+                                                    d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st, packed));
             if (ev_[3]) DTL_HIP_CHECK(hipEventRecord(ev_[3], st));
             DTL_TRY(launch_tb_check(d_tbdesc_.as<TbDesc>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
-                                    d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st));
+                                    d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st, packed));
             DTL_TRY(d_payload.ensure(max_out_bytes + 64));
             DTL_TRY(launch_compact(d_staging_.as<uint8_t>(), stride, d_len_.as<int32_t>(), n_tbs, d_offs_.as<uint32_t>(),
                                    d_total_.as<uint32_t>(), d_payload.as<uint8_t>(), st));

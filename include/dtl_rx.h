@@ -180,7 +180,8 @@ typedef struct dtl_rx_result {
     const float* d_taps;        /* per visited trigger: N taps handed to the payload equaliser */
     const uint8_t* d_hdr_bits;
     const float* d_metric;
-    const uint8_t* d_cw_bits;
+    const uint8_t* d_cw_bits;   /* decoded bits of the transport blocks, packed LSB first (1 byte per bit for codes the
+                                 * node-parallel kernel does not serve) */
     const int32_t* d_cw_nit;
     double stage_ms[8];
     int32_t frame_capacity, hdr_bits, frame_samples, pad;
