@@ -549,10 +549,13 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             // 1 bit per bit, LSB first (what fec_pack / the CRC check want): 64 decisions per ballot, OR-ed into the
             // zeroed output words at bit position out_off (codewords of a block are not byte aligned in general)
             unsigned long long* words = reinterpret_cast<unsigned long long*>(out_bits);
+            const bool bytewise = ((out_off | unsigned(k_used)) & 7u) == 0;  // the usual case: whole bytes, plain stores
             for (int i0 = 0; i0 < k_used; i0 += kWave) {
                 const int i = i0 + lane;
                 const unsigned long long w = __ballot(i < k_used && est[sys_src[i < k_used ? i : 0]] != 0);
-                if (lane == 0 && w) {
+                if (bytewise) {
+                    if (lane < 8 && i0 + 8 * lane < k_used) out_bits[(size_t(out_off) + size_t(i0)) / 8 + lane] = uint8_t(w >> (8 * lane));
+                } else if (lane == 0 && w) {
                     const unsigned long long pos = (unsigned long long)(out_off) + (unsigned long long)(i0);
                     const unsigned sh = unsigned(pos & 63ull);
                     atomicOr(&words[pos >> 6], w << sh);
