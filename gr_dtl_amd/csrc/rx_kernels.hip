@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     // store, load, ...: one exposed memory latency per 512 samples of the tile).
     {
         constexpr int kTileIters = R;                                  // kSyncTile / kSyncThreads
-        constexpr int kHistIters = R == 8 ? 2 : 6;                     // (N + N/2) / kSyncThreads for the largest N served
+        constexpr int kHistIters = ((R == 8 ? 768 : 1536) + kSyncThreads - 1) / kSyncThreads; // (N + N/2) / threads, largest N served
         cf32 stage[kTileIters + kHistIters];
 #pragma unroll
         for (int it = 0; it < kTileIters + kHistIters; it++) {
