@@ -217,42 +217,48 @@ def decode_stats(rx, x, res, n_user):
             "codewords": int(res.n_codewords), "payload_bytes": int(res.n_payload_bytes), "user_bytes_sent": int(n_user)}
 
 
-def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2):
+def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2, gloo=False):
     """SURVEY 8(e) "report both": ONE rank holds the whole stream (world x the per-GPU batch), scatter over xGMI ->
     decode -> gather; times of the three phases, max over ranks (tools/root_fed.py is the stand-alone form)."""
     import torch
     from gr_dtl_amd.sharding import combine, gather_results, owned_payload, scatter_stream
     rank, world = dist.get_rank(), dist.get_world_size()
-    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    exch = None if gloo else device          # gloo rehearsal (ranks share one GPU): the exchange is staged through the host
+    meta = torch.zeros(2, dtype=torch.int64, device=exch)
     x = None
     if rank == 0:
         x, n_frames, _, _ = synth_stream(dtl, cfg, w, frames_per_gpu * world, device, seed=1000)
         meta[0], meta[1] = n_frames, x.numel()
+        if gloo:
+            x = x.cpu()
     dist.broadcast(meta, 0)
     n_frames, total = int(meta[0]), int(meta[1])
     best = None
     for _ in range(1 + steps):                                # first pass = warm-up (RCCL channel set-up)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        mine, plan = scatter_stream(x, n_frames, rx.frame_samples, 100, total, dist, device=device)
+        mine, plan = scatter_stream(x, n_frames, rx.frame_samples, 100, total, dist, device=exch)
+        mine = mine.to(device)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         res = rx.work(mine)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        data, tbs = owned_payload(res, plan, on_device=True)
-        got, recs = gather_results(data, tbs, dist, device=device)
+        data, tbs = owned_payload(res, plan, on_device=not gloo)
+        got, recs = gather_results(data, tbs, dist, device=exch)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         del mine
         cur = (t1 - t0, t2 - t1, t3 - t2)
         if best is None or sum(cur) < sum(best[:3]):
-            best = cur + (int(got.numel()) if got is not None else 0, int(len(recs)) if recs is not None else 0)
-    (ts, _), (td, _), (tg, _) = (combine(v, [0], dist, device) for v in best[:3])
+            n_got = 0 if got is None else int(got.numel() if hasattr(got, "numel") else got.size)
+            best = cur + (n_got, int(len(recs)) if recs is not None else 0)
+    (ts, _), (td, _), (tg, _) = (combine(v, [0], dist, exch) for v in best[:3])
     return {"frames": n_frames, "samples": total, "scatter_ms": round(ts * 1e3, 3), "decode_ms": round(td * 1e3, 3),
             "gather_ms": round(tg * 1e3, 3), "msamples_per_s_decode_only": round(total / td / 1e6, 1),
             "msamples_per_s_with_exchange": round(total / (ts + td + tg) / 1e6, 1),
-            "payload_bytes": best[3], "blocks": best[4], "backend": "nccl (RCCL, point-to-point over xGMI)"}
+            "payload_bytes": best[3], "blocks": best[4],
+            "backend": "gloo (host-staged rehearsal)" if gloo else "nccl (RCCL, point-to-point over xGMI)"}
 
 
 def main():
@@ -404,7 +410,7 @@ def main():
                                  "see `saturated` for its instruction-bound fraction"},
             "stats": st,
         }
-    if not args.no_extras and not rehearsal:
+    if not args.no_extras:
         if rank == 0 and world == 1:
             # (2) the decoder kernel under load (~9 iterations per codeword), both arithmetics
             sat = {a: decoder_under_load(dtl, device, a) for a in ("gr_exact", "fast")}
@@ -441,7 +447,7 @@ def main():
             timer.start()
             try:
                 del x
-                rf = root_fed_record(dtl, cfg, w, rx, n_frames_req, dist, device)
+                rf = root_fed_record(dtl, cfg, w, rx, n_frames_req, dist, device, gloo=bool(rehearsal))
                 if rank == 0:
                     extras["root_fed"] = rf
             except Exception as e:  # the headline must survive a failure of the secondary record
