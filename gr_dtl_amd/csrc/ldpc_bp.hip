@@ -332,16 +332,27 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     // to 30 % more work than the average.  (One ticket per codeword would serialise millions of
     // same-address device-scope atomics: measured 2.3x slower.)  The next codeword is known before
     // the current one is decoded so that its soft bits can be prefetched.
-    const int n_chunks = (ncw + chunk - 1) / chunk;
+    // Tickets: `n_big` chunks of `chunk` codewords, then the last codewords in chunks of `kTailChunk` -- a wave that
+    // takes a 16-codeword ticket near the end would still be decoding (~1 ms) when every other wave has run out of work
+    constexpr int kTailChunk = 2;
+    const int tail_cw = chunk > kTailChunk ? min(ncw, int(gridDim.x) * kNpWaves * 8) : 0;
+    const int n_big = (ncw - tail_cw) / chunk;                  // codewords [0, n_big * chunk) in big chunks
+    const int tail_first = n_big * chunk;
+    const int n_tail = (ncw - tail_first + kTailChunk - 1) / kTailChunk;
     int chunk_next = 0, chunk_end = 0;
     auto advance = [&]() -> int {
         if (chunk_next == chunk_end) {
             unsigned v = 0;
             if (lane == 0) v = atomicAdd(queue, 1u);
             v = __builtin_amdgcn_readfirstlane(v);
-            if (v >= unsigned(n_chunks)) return ncw;
-            chunk_next = int(v) * chunk;
-            chunk_end = min(chunk_next + chunk, ncw);
+            if (v >= unsigned(n_big + n_tail)) return ncw;
+            if (int(v) < n_big) {
+                chunk_next = int(v) * chunk;
+                chunk_end = chunk_next + chunk;
+            } else {
+                chunk_next = tail_first + (int(v) - n_big) * kTailChunk;
+                chunk_end = min(chunk_next + kTailChunk, ncw);
+            }
         }
         return chunk_next++;
     };
