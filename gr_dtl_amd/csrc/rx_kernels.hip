@@ -1045,12 +1045,25 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     const float npwr = float(sqrt(stats[f].noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
     const float rinv = float(1.0 / double(npwr));        // the correctly rounded single reciprocal
     const cf32 s = soft_syms[size_t(f) * t.frame_capacity + q];
-    float* o = llr_out + size_t(llr_off[f]) + size_t(q) * bps;
+    const uint32_t base = llr_off[f];
+    float* dst = llr_out + size_t(base) + size_t(q) * bps;
+    float o[4];
     switch (bps) {
-    case 1: soft_demap_symbol<1, MODE>(s, pts, npwr, rinv, o); break;
-    case 2: soft_demap_symbol<2, MODE>(s, pts, npwr, rinv, o); break;
-    case 3: soft_demap_symbol<3, MODE>(s, pts, npwr, rinv, o); break;
-    default: soft_demap_symbol<4, MODE>(s, pts, npwr, rinv, o); break;
+    case 1: soft_demap_symbol<1, MODE>(s, pts, npwr, rinv, o); dst[0] = o[0]; break;
+    case 2:
+        soft_demap_symbol<2, MODE>(s, pts, npwr, rinv, o);
+        // a symbol's soft bits leave in ONE store when the frame's position in the stream allows it (a frame starts
+        // wherever the previous ones ended): four dword stores at a 16-byte stride make the memory pipeline handle
+        // 64 four-byte pieces each
+        if ((base & 1u) == 0) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+        else { dst[0] = o[0]; dst[1] = o[1]; }
+        break;
+    case 3: soft_demap_symbol<3, MODE>(s, pts, npwr, rinv, o); dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; break;
+    default:
+        soft_demap_symbol<4, MODE>(s, pts, npwr, rinv, o);
+        if ((base & 3u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
+        break;
     }
 }
 

@@ -599,10 +599,12 @@ int Receiver::upload_tables()
     std::vector<uint8_t> pmask(size_t(std::max(n_pilot_sets, 1)) * N, 0);
     std::vector<cf32> pval(size_t(n_psym) * N, cf32{ 0, 0 });
     for (int s = 0; s < n_pilot_sets; s++)
-        for (int k = 0; k < n_pilots; k++) pmask[size_t(s) * N + shifted(cfg.pilot_carriers[s][k])] = 1;
+        for (int k = 0; k < n_pilots; k++)
+            if (cfg.pilot_carriers[s][k] != DTL_NO_CARRIER) pmask[size_t(s) * N + shifted(cfg.pilot_carriers[s][k])] = 1;
     for (size_t s = 0; s < cfg.pilot_symbols.size(); s++) { // equalizer.cc:196-214: all symbol sets are loaded
         const int cset = int(s % std::max(n_pilot_sets, 1));
-        for (int k = 0; k < n_pilots; k++) pval[s * N + shifted(cfg.pilot_carriers[cset][k])] = cfg.pilot_symbols[s][k];
+        for (int k = 0; k < n_pilots; k++)
+            if (cfg.pilot_carriers[cset][k] != DTL_NO_CARRIER) pval[s * N + shifted(cfg.pilot_carriers[cset][k])] = cfg.pilot_symbols[s][k];
     }
     // ofdm_chanest_vcvc ctor
     std::vector<cf32> corr(N), ref(cfg.sync_word2);

@@ -147,7 +147,8 @@ int Transmitter::upload_tables()
     const int n_psym = int(cfg.pilot_symbols.size());
     std::vector<int16_t> pil_rank(size_t(std::max(n_pilot_sets, 1)) * N, -1);
     for (int s = 0; s < n_pilot_sets; s++)
-        for (int k = 0; k < n_pilots; k++) pil_rank[size_t(s) * N + shifted(cfg.pilot_carriers[s][k])] = int16_t(k);
+        for (int k = 0; k < n_pilots; k++)
+            if (cfg.pilot_carriers[s][k] != DTL_NO_CARRIER) pil_rank[size_t(s) * N + shifted(cfg.pilot_carriers[s][k])] = int16_t(k);
     std::vector<cf32> psyms(size_t(std::max(n_psym, 1)) * std::max(n_pilots, 1), cf32{ 0, 0 });
     for (int s = 0; s < n_psym; s++)
         for (int k = 0; k < n_pilots; k++) psyms[size_t(s) * n_pilots + k] = cfg.pilot_symbols[s][k];

@@ -49,8 +49,14 @@ def make_cfg_struct(cfg):
     occ = np.zeros((len(cfg.occupied_carriers), max_occ), dtype=np.int32)
     for i, o in enumerate(cfg.occupied_carriers):
         occ[i, :len(o)] = o
-    pil = np.ascontiguousarray(cfg.pilot_carriers, dtype=np.int32)
-    psym = np.ascontiguousarray(np.asarray(cfg.pilot_symbols, dtype=np.complex64))
+    # pilot sets may differ in size: padded with DTL_NO_CARRIER / 0
+    npil = max([len(p) for p in cfg.pilot_carriers] + [1])
+    pil = np.full((len(cfg.pilot_carriers), npil), 0x7fffffff, dtype=np.int32)
+    for i, pset in enumerate(cfg.pilot_carriers):
+        pil[i, :len(pset)] = list(pset)
+    psym = np.zeros((len(cfg.pilot_symbols), npil), dtype=np.complex64)
+    for i, row in enumerate(cfg.pilot_symbols):
+        psym[i, :len(row)] = list(row)
     sw1 = np.ascontiguousarray(np.asarray(cfg.sync_word1, dtype=np.complex64))
     sw2 = np.ascontiguousarray(np.asarray(cfg.sync_word2, dtype=np.complex64))
     texts = []

@@ -105,6 +105,7 @@ int dtl_ldpc_decode_gather(const dtl_ldpc* h, const float* d_llr, const dtl_cw_d
  * ------------------------------------------------------------------------------------------ */
 typedef struct dtl_rx dtl_rx;
 
+#define DTL_NO_CARRIER 0x7fffffff
 /* dataclass ofdm_adaptive_config / ofdm_adaptive_rx_config (python/dtl/ofdm_adaptive_config.py:10-63) */
 typedef struct dtl_rx_cfg {
     int32_t fft_len, cp_len, frame_length, has_fec;
@@ -112,7 +113,7 @@ typedef struct dtl_rx_cfg {
     const int32_t* occ_len;          /* n_occ_sets */
     const int32_t* occ;              /* n_occ_sets x max_occ, signed carrier indices */
     int32_t n_pilot_sets, n_pilots;
-    const int32_t* pilot_carriers;   /* n_pilot_sets x n_pilots */
+    const int32_t* pilot_carriers;   /* n_pilot_sets x n_pilots; DTL_NO_CARRIER pads a set with fewer pilots */
     int32_t n_pilot_sym_sets;
     const float* pilot_symbols;      /* n_pilot_sym_sets x n_pilots complex (re,im) */
     const float* sync_word1;         /* fft_len complex (re,im), shifted (DC at N/2) */

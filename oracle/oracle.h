@@ -199,7 +199,8 @@ typedef struct {
     const int* occ_len;            /* n_occ_sets                              */
     const int* occ;                /* n_occ_sets x max_occ, signed carrier idx */
     int n_pilot_sets, n_pilots;
-    const int* pilot_carriers;     /* n_pilot_sets x n_pilots                 */
+    const int* pilot_carriers;     /* n_pilot_sets x n_pilots; ORC_NO_CARRIER pads a set that has fewer pilots (the
+                                    * reference's sets may differ in size, qa_ofdm_adaptive_frame_equalizer_vcvc.py:81) */
     int n_pilot_sym_sets;
     const orc_c32* pilot_symbols;  /* n_pilot_sym_sets x n_pilots             */
     const orc_c32* sync1;          /* fft_len, shifted (DC at N/2)            */
@@ -214,6 +215,7 @@ typedef struct {
     int arith;                     /* 0: gr_exact (the reference's operations), 1: fast (BP + 16-QAM demapper) */
 } orc_cfg;
 
+#define ORC_NO_CARRIER 0x7fffffff
 /* python/dtl/ofdm_adaptive.py:1-6 */
 int orc_frame_capacity(const orc_cfg* cfg);
 

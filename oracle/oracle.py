@@ -143,6 +143,7 @@ def decision_maker(cnst, samples):
                     dtype=np.uint8)
 
 
+NO_CARRIER = 0x7fffffff         # oracle.h: ORC_NO_CARRIER
 GR_EXACT, FAST = 0, 1           # arithmetic modes (oracle.h: orc_cfg.arith); DEMAP_FAST is the flag on dist_mode
 DEMAP_FAST = 0x100
 
@@ -360,7 +361,10 @@ class Config:
         self.frame_length = frame_length
         self.has_fec = bool(has_fec)
         self.header_len = 2 if has_fec else 1   # ofdm_receiver.py:66-68
-        occ, pil, psym = default_carriers(fft_len)
+        if occupied_carriers is None or pilot_carriers is None or pilot_symbols is None:
+            occ, pil, psym = default_carriers(fft_len)
+        else:
+            occ = pil = psym = None
         self.occupied_carriers = occupied_carriers if occupied_carriers is not None else occ
         self.pilot_carriers = pilot_carriers if pilot_carriers is not None else pil
         self.pilot_symbols = pilot_symbols if pilot_symbols is not None else psym
@@ -381,8 +385,14 @@ class Config:
         self._occ = np.zeros((nocc, mo), dtype=np.int32)
         for i, o in enumerate(self.occupied_carriers):
             self._occ[i, :len(o)] = o
-        self._pil = np.ascontiguousarray(self.pilot_carriers, dtype=np.int32)
-        self._psym = np.ascontiguousarray(self.pilot_symbols, dtype=c32)
+        # pilot sets may differ in size (the reference's equaliser QA uses empty ones): padded with NO_CARRIER / 0
+        npil = max([len(p) for p in self.pilot_carriers] + [1])
+        self._pil = np.full((len(self.pilot_carriers), npil), NO_CARRIER, dtype=np.int32)
+        for i, pset in enumerate(self.pilot_carriers):
+            self._pil[i, :len(pset)] = list(pset)
+        self._psym = np.zeros((len(self.pilot_symbols), npil), dtype=c32)
+        for i, row in enumerate(self.pilot_symbols):
+            self._psym[i, :len(row)] = list(row)
         c = Cfg()
         c.fft_len, c.cp_len, c.frame_length = self.fft_len, self.cp_len, self.frame_length
         c.header_len, c.has_fec = self.header_len, int(self.has_fec)

@@ -130,9 +130,11 @@ void orc_tx_frame(const orc_cfg* cfg, const uint8_t* hdr_bits, const uint8_t* pa
                 else freq[idx] = pts[payload_syms[pay_pos++]];                      /* map_to_points */
             }
             int pset = i % cfg->n_pilot_sets;
-            for (int k = 0; k < cfg->n_pilots; k++)
+            for (int k = 0; k < cfg->n_pilots; k++) {
+                if (cfg->pilot_carriers[pset * cfg->n_pilots + k] == ORC_NO_CARRIER) continue;
                 freq[shifted_index(cfg->pilot_carriers[pset * cfg->n_pilots + k], N)] =
                     cfg->pilot_symbols[(i % cfg->n_pilot_sym_sets) * cfg->n_pilots + k];
+            }
         }
         orc_fft_shifted(freq, time, N, 0);
         /* ofdm_cyclic_prefixer, rolloff 0 */
@@ -361,13 +363,15 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
     uint8_t* pilot_mask = (uint8_t*)calloc((size_t)cfg->n_pilot_sets * N, 1);
     for (int s = 0; s < cfg->n_pilot_sets; s++)
         for (int k = 0; k < cfg->n_pilots; k++)
-            pilot_mask[s * N + shifted_index(cfg->pilot_carriers[s * cfg->n_pilots + k], N)] = 1;
+            if (cfg->pilot_carriers[s * cfg->n_pilots + k] != ORC_NO_CARRIER)
+                pilot_mask[s * N + shifted_index(cfg->pilot_carriers[s * cfg->n_pilots + k], N)] = 1;
     cf* pilot_sym = (cf*)calloc((size_t)cfg->n_pilot_sym_sets * N, sizeof(cf));
     for (int s = 0; s < cfg->n_pilot_sym_sets; s++) {
         int cset = s % cfg->n_pilot_sets;
         for (int k = 0; k < cfg->n_pilots; k++)
-            pilot_sym[s * N + shifted_index(cfg->pilot_carriers[cset * cfg->n_pilots + k], N)] =
-                to_cf(cfg->pilot_symbols[s * cfg->n_pilots + k]);
+            if (cfg->pilot_carriers[cset * cfg->n_pilots + k] != ORC_NO_CARRIER)
+                pilot_sym[s * N + shifted_index(cfg->pilot_carriers[cset * cfg->n_pilots + k], N)] =
+                    to_cf(cfg->pilot_symbols[s * cfg->n_pilots + k]);
     }
     /* header: ctor passes (symbols_skipped, input_is_shifted, alpha) into (symbols_skipped, alpha,
      * input_is_shifted) => alpha = 1.0 (equalizer.cc:147-154); the Python call gives

@@ -183,3 +183,40 @@ def test_txrx_round_trip_noise_free(oracle):
         assert _check_tbs(r, user, 10, "tb") == n_tb, thr
         assert all(t["avg_it"] == 0 for t in r["tbs"])
         assert np.array_equal(r["user_bytes"][:user.size], user), thr
+
+
+def test_frame_equalizer_slicing_and_feedback(oracle):
+    """qa_ofdm_adaptive_frame_equalizer_vcvc.py:63-165: fft_len 8, carriers (1, 2, 6, 7), four symbols of which the third
+    is all pilots, channel = per-carrier phases (a step of +-0.05 pi in the second symbol, j in the last two), noise
+    sigma 0.001, alpha 0.01, QPSK and 8PSK.  The reference asserts (a) the equalised and sliced symbols are the
+    transmitted ones and (b) the feedback message after the frame is {constellation: 1 (BPSK), fec: 0} with the
+    default MCS table and a decision counter of 3.  The reference passes symbols_skipped = 0; the oracle's payload
+    equaliser skips header_len = 1 symbol, so the pilot sets are rotated by one (set (1 + i) % 4 serves symbol i: the all-pilot symbol 2 is set 3)."""
+    want = G["frame_equalizer_qa"]
+    rng = np.random.default_rng(123)
+    fft_len, occ = want["fft_len"], tuple(want["occupied_carriers"])
+    tx_data = np.array(want["tx_data"])
+    for cnst in (oracle.QPSK, oracle.PSK8):
+        pts = oracle.constellation_points(cnst)
+        if cnst == oracle.QPSK:                      # the QA maps with GR's own (unscaled) QPSK
+            pts = pts / np.abs(pts[0]) * 1.0
+        tx = np.array([pts[x] if x >= 0 else 0 for x in tx_data], dtype=np.complex64)
+        pil_syms = [pts[x] for x in want["pilot_data"]]
+        cfg = oracle.Config(fft_len=fft_len, cp_len=2, frame_length=4, has_fec=False, eq_alpha=want["alpha"],
+                            occupied_carriers=(occ,), pilot_carriers=((), (), (), occ),
+                            pilot_symbols=([], [], [], pil_syms),
+                            sync_word1=np.ones(fft_len, np.complex64), sync_word2=np.ones(fft_len, np.complex64))
+        chan = np.array(want["channel"], dtype=np.complex128).view(np.complex128)
+        chan = chan[0::2] + 1j * chan[1::2]
+        chan[fft_len:2 * fft_len] = chan[:fft_len] * np.exp(1j * 0.1 * np.pi * (rng.random(fft_len) - 0.5))
+        noise = np.where(tx != 0, rng.normal(0, 0.001, tx.size), 0)
+        rx = (tx * chan + noise).astype(np.complex64)
+        hard, soft, taps, (snr_db, noise_db, noise_lin) = oracle.frame_equalize(cfg, False, cnst, rx, 0, chan[:fft_len])
+        # (a) demod(out_syms) == tx_data, unused carriers stay 0
+        dpts = oracle.constellation_points(cnst)
+        got = [int(np.argmin(np.abs(dpts - v))) if v != 0 else -1 for v in hard.reshape(-1)]
+        assert got == list(tx_data), cnst
+        # (b) one frame through the feedback decision: still the initial MCS (BPSK, no FEC)
+        fb = oracle.FeedbackDecision(1, 3, [(m[0], (m[1], 0)) for m in want["default_mcs"]], 0)
+        assert fb.get_feedback(snr_db) == (want["feedback"]["constellation"], want["feedback"]["fec"])
+        assert snr_db > 20.0

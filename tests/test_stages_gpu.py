@@ -201,3 +201,49 @@ def test_tb_gather_matches_receiver_and_oracle(oracle, dtl, cuda, cnst, esn0, fr
         if crc_ok:
             np.testing.assert_array_equal(by[:-4], payload[t["out_offset"]:t["out_offset"] + t["user_bits"] // 8])
     assert sum(int(t["crc_ok"]) for t in res.tbs) >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cnst", [2, 3, 4])
+def test_equalizer_with_pilot_sets_of_different_sizes(oracle, dtl, cuda, cnst):
+    """The carrier plan of the reference's own equaliser QA (qa_ofdm_adaptive_frame_equalizer_vcvc.py:80-85) has pilot
+    sets of different sizes -- three empty ones and one that takes every carrier -- which the flattened C-ABI tables pad
+    with DTL_NO_CARRIER.  Same structure at 64 carriers: dtl_equalize_frames against the oracle's frame equaliser."""
+    import torch
+    rng = np.random.default_rng(60 + cnst)
+    pcfg = dtl.ofdm_adaptive_rx_config(frame_length=6)
+    occ = tuple(pcfg.occupied_carriers[0])
+    pil = tuple(pcfg.pilot_carriers[0])
+    pcfg.pilot_carriers = (pil, (), pil[:2], occ[:8] + pil)          # 4, 0, 2 and 12 pilots
+    pcfg.pilot_symbols = tuple(tuple(complex(v) for v in rng.choice([-1.0, 1.0], len(p))) for p in pcfg.pilot_carriers)
+    pcfg.fec_codes = (("fec_1", "n_0300_k_0152_gap_03.alist"),)
+    pcfg.mcs = ((-100000, (dtl.constellation_type_t.BPSK, "fec_1")), (11, (dtl.constellation_type_t.QPSK, "fec_1")))
+    ocfg = oracle.Config(fft_len=64, cp_len=16, frame_length=6, has_fec=True, occupied_carriers=pcfg.occupied_carriers,
+                         pilot_carriers=pcfg.pilot_carriers, pilot_symbols=pcfg.pilot_symbols,
+                         sync_word1=pcfg.sync_word1, sync_word2=pcfg.sync_word2)
+    rx = dtl.ofdm_receiver(pcfg)
+    n, L, N = 12, 6, 64
+    pts = oracle.constellation_points(cnst)
+    frames = np.zeros((n, L, N), np.complex64)
+    taps = np.zeros((n, N), np.complex64)
+    shifted = lambda c: ((c + N) % N + N // 2) % N
+    for f in range(n):
+        h = np.exp(1j * rng.uniform(-0.4, 0.4, N)) * rng.uniform(0.8, 1.2, N)
+        taps[f] = h.astype(np.complex64)
+        for i in range(L):
+            pset = pcfg.pilot_carriers[(2 + i) % 4]                 # symbols_skipped = header_len = 2
+            psym = pcfg.pilot_symbols[(2 + i) % 4]
+            for c in occ:
+                frames[f, i, shifted(c)] = pts[rng.integers(0, len(pts))]
+            for c, v in zip(pset, psym):
+                frames[f, i, shifted(c)] = v
+            drift = np.exp(1j * 0.02 * (i + 1))
+            frames[f, i] = frames[f, i] * h * drift + (frames[f, i] != 0) * (rng.normal(0, 0.02, N) + 1j * rng.normal(0, 0.02, N))
+    hard, soft, syms, stats = rx.equalize_frames(torch.from_numpy(frames).to(cuda), torch.from_numpy(taps).to(cuda),
+                                                 [cnst] * n, [0] * n, [rx.frame_capacity] * n)
+    hard, soft = hard.cpu().numpy(), soft.cpu().numpy()
+    for f in range(n):
+        h_ref, s_ref, t_ref, (snr_db, noise_db, noise_lin) = oracle.frame_equalize(ocfg, False, cnst, frames[f], 0, taps[f])
+        np.testing.assert_array_equal(hard[f], h_ref.reshape(L, N))
+        np.testing.assert_allclose(soft[f], s_ref.reshape(L, N), rtol=1e-5, atol=2e-6)
+        assert abs(stats["snr_db"][f] - snr_db) <= 1e-6 * abs(snr_db) + 1e-6
