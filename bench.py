@@ -55,7 +55,7 @@ def build_config(dtl, w):
     return cfg
 
 
-def synth_stream(dtl, cfg, w, n_frames, device, seed):
+def synth_stream(dtl, cfg, w, n_frames, device, seed, lead=True, tail=True):
     """Synthetic AWGN IQ frames of the named FFT/codeword sizes: independent random payload for every frame,
     framed / LDPC-encoded / OFDM-modulated on the GPU by the product's own transmitter
     (gr_dtl_amd.ofdm_transmitter.work_device), 100 leading zeros, one frame of trailing zeros, plus
@@ -75,9 +75,14 @@ def synth_stream(dtl, cfg, w, n_frames, device, seed):
     n_user = int(n_frames * frame_bytes / tb_coded_bytes) * tb_payload
     user = torch.randint(0, 256, (n_user,), dtype=torch.uint8, device=device, generator=g)
     iq, hdrs, _ = tx.work_device(user, w["cnst"], "fec_1")
-    lead = torch.zeros(100, dtype=torch.complex64, device=device)             # qa_ofdm_adaptive_txrx.py:82-83
-    tail = torch.zeros(tx.frame_samples, dtype=torch.complex64, device=device)
-    x = torch.cat([lead, iq.reshape(-1), tail])
+    # 100 zeros in front (qa_ofdm_adaptive_txrx.py:82-83), one frame of zeros behind; a stream assembled from several
+    # calls (the transmitter's 32-bit offsets end at ~4 G coded bits: 256 k frames of C3) takes them once
+    parts = [iq.reshape(-1)]
+    if lead:
+        parts.insert(0, torch.zeros(100, dtype=torch.complex64, device=device))
+    if tail:
+        parts.append(torch.zeros(tx.frame_samples, dtype=torch.complex64, device=device))
+    x = torch.cat(parts) if len(parts) > 1 else parts[0].clone()
     del iq
     nv = w["fft_len"] * ES[w["cnst"]] / 10 ** (w["esn0_db"] / 10)
     g.manual_seed(1234 + seed)
@@ -227,7 +232,14 @@ def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2, gloo
     meta = torch.zeros(2, dtype=torch.int64, device=exch)
     x = None
     if rank == 0:
-        x, n_frames, _, _ = synth_stream(dtl, cfg, w, frames_per_gpu * world, device, seed=1000)
+        # one piece per rank's share (block / frame numbers restart per piece, as after a transmitter restart)
+        pieces, n_frames = [], 0
+        for r in range(world):
+            xr, nf, _, _ = synth_stream(dtl, cfg, w, frames_per_gpu, device, seed=1000 + r, lead=(r == 0), tail=(r == world - 1))
+            pieces.append(xr)
+            n_frames += nf
+        x = torch.cat(pieces) if world > 1 else pieces[0]
+        del pieces
         meta[0], meta[1] = n_frames, x.numel()
         if gloo:
             x = x.cpu()

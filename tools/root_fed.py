@@ -49,7 +49,13 @@ def main():
     meta = torch.zeros(2, dtype=torch.int64, device="cpu" if gloo else device)
     x = None
     if rank == 0:
-        x, n_frames, _, _ = bench.synth_stream(dtl, cfg, w, args.frames_per_gpu * world, device, seed=0)
+        pieces, n_frames = [], 0      # one piece per rank's share: the transmitter's 32-bit offsets end at ~256 k C3 frames
+        for r in range(world):
+            xr, nf, _, _ = bench.synth_stream(dtl, cfg, w, args.frames_per_gpu, device, seed=r, lead=(r == 0), tail=(r == world - 1))
+            pieces.append(xr)
+            n_frames += nf
+        x = torch.cat(pieces) if world > 1 else pieces[0]
+        del pieces
         meta[0], meta[1] = n_frames, x.numel()
     dist.broadcast(meta, 0)
     n_frames, total = int(meta[0]), int(meta[1])
