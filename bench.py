@@ -185,7 +185,7 @@ def decoder_under_load(dtl, device, arith, ncw=1 << 20, esn0_db=-1.0, reps=3):
 
 # wave instructions in one belief-propagation iteration of ldpc_bp_np_kernel<6,3,5,true,*> (tools/isa_loops.py on the
 # built code object; profiles/r02/ldpc_isa_counts.txt)
-LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 1070, "fast": 706}
+LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 960, "fast": 706}
 
 
 def timed_steps(rx, x, steps, warmup, barrier):
