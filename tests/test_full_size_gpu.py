@@ -18,6 +18,26 @@ sys.path.insert(0, ROOT)
 
 
 @pytest.mark.gpu
+def test_c1_plumbing_full_size_matches_oracle(oracle, dtl, cuda):
+    """configs[0] on the GPU path as well: 64-point FFT, BPSK, no FEC, 1000 frames, Es/N0 20 dB -- frames, CRC flags and
+    bytes identical to the oracle; noise-free: every user byte back."""
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, fec=None)
+    per = ocfg.frame_capacity // 8 - 4
+    for esn0 in (None, 20.0):
+        user, hdrs, x = make_stream(oracle, ocfg, None, 1, 1000 * per, esn0, seed=1)
+        assert len(hdrs) == 1000
+        rx = dtl.ofdm_receiver(pcfg)
+        res = rx.work(torch.from_numpy(x).to(cuda))
+        ref = oracle.rx_stream(ocfg, None, x, feedback=oracle_feedback(oracle, pcfg, rx), want=("frames",))
+        assert len(res.frames) == ref["n_frames"] >= 1000
+        assert [(int(t["tb_no"]), int(t["crc_ok"])) for t in res.tbs] == [(t["tb_no"], t["crc_ok"]) for t in ref["tbs"]]
+        np.testing.assert_array_equal(res.payload.cpu().numpy(), ref["user_bytes"])
+        if esn0 is None:
+            np.testing.assert_array_equal(ref["user_bytes"], user)
+
+
+@pytest.mark.gpu
 def test_c2_full_batch_matches_oracle(oracle, dtl, cuda):
     import torch
     pcfg, ocfg, code = make_pair(oracle, dtl)

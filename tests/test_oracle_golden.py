@@ -220,3 +220,19 @@ def test_frame_equalizer_slicing_and_feedback(oracle):
         fb = oracle.FeedbackDecision(1, 3, [(m[0], (m[1], 0)) for m in want["default_mcs"]], 0)
         assert fb.get_feedback(snr_db) == (want["feedback"]["constellation"], want["feedback"]["fec"])
         assert snr_db > 20.0
+
+
+def test_config1_plumbing_round_trip_full_size(oracle):
+    """BASELINE.json configs[0] (the reference's ofdm_adaptive_example.grc loopback, CPU only): 64-point FFT, BPSK, no FEC,
+    1000 frames of 20 OFDM symbols = 1.84 M samples, noise-free -- every user byte back, in order."""
+    cfg = oracle.Config(frame_length=20, has_fec=False)
+    per = cfg.frame_capacity // 8 - 4
+    rng = np.random.default_rng(1)
+    user = rng.integers(0, 256, 1000 * per).astype(np.uint8)
+    syms, hdrs = oracle.nofec_frames_build(oracle.BPSK, cfg.frame_capacity, user)
+    assert len(hdrs) == 1000
+    x = oracle.awgn_stream(oracle.tx_frames(cfg, syms, hdrs), 0.0, 0)
+    assert x.size == 100 + 1001 * cfg.frame_samples
+    r = oracle.rx_stream(cfg, None, x)
+    assert _check_tbs(r, user, per, "frame") == 1000
+    assert np.array_equal(r["user_bytes"], user)
