@@ -192,7 +192,7 @@ typedef struct dtl_rx_result {
  * work-queue counter; dtl_ldpc_set_arith must not run concurrently with a decode).
  * dtl_rx / dtl_tx: one handle serves one call at a time (it owns its device buffers, staging memory and stream
  * state); different handles may run concurrently from different host threads on different HIP streams
- * (bench.py --in-flight 2 does that to overlap one batch's host phases with another's decoder kernels). */
+ * (two receivers decoding alternate batches overlap one batch's host phases with the other's decoder kernels). */
 int dtl_rx_create(const dtl_rx_cfg* cfg, dtl_rx** out);
 void dtl_rx_destroy(dtl_rx* h);
 /* d_iq: n_samples complex64 (re,im) on the device */
