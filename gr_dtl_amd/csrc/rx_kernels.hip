@@ -281,6 +281,28 @@ constexpr int kSyncTile = kSyncTileSamples;   // the stream carry is aligned to 
 template <int R>
 __device__ __forceinline__ int sync_pad(int j) { return j + (j >> 4); }
 
+// Inclusive scan of a double over the 64 lanes of a wave with data-parallel-primitive moves (no LDS crossbar, no lane
+// selects): four shifts inside the rows of 16 lanes (zero fill at the row start), then the last lane of rows 0 / 2
+// added to rows 1 / 3 (row_bcast:15) and lane 31 to the upper half (row_bcast:31).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan(double x)
+{
+    x += dpp_take<0x111, 0xf>(x);   // row_shr:1
+    x += dpp_take<0x112, 0xf>(x);   // row_shr:2
+    x += dpp_take<0x114, 0xf>(x);   // row_shr:4
+    x += dpp_take<0x118, 0xf>(x);   // row_shr:8
+    x += dpp_take<0x142, 0xa>(x);   // row_bcast:15 -> rows 1, 3
+    x += dpp_take<0x143, 0xc>(x);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 template <bool WITH_METRIC, int R>
 __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R == 8 ? 6 : 2))) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
                                                                  int64_t m_begin, int N, float thr,
@@ -314,13 +336,22 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         constexpr int kTileIters = R;                                  // kSyncTile / kSyncThreads
         constexpr int kHistIters = ((R == 8 ? 768 : 1536) + kSyncThreads - 1) / kSyncThreads; // (N + N/2) / threads, largest N served
         cf32 stage[kTileIters + kHistIters];
+        // interior tiles (all but the first and the last of a stream) load without any bounds handling; an iteration
+        // that lies entirely behind the staged range (N smaller than the largest N served) is skipped by every thread
+        const bool interior = b0 >= 0 && b0 + int64_t(kTileIters + kHistIters) * kSyncThreads <= n;
+        if (interior) {
 #pragma unroll
-        for (int it = 0; it < kTileIters + kHistIters; it++) {
-            const int q = tid + it * kSyncThreads;
-            const int64_t j = b0 + q;
-            const bool inside = q < n_raw && j >= 0 && j < n;
-            const cf32 v = iq[inside ? j : 0];
-            stage[it] = cf32{ inside ? v.re : 0.0f, inside ? v.im : 0.0f };
+            for (int it = 0; it < kTileIters + kHistIters; it++)
+                if (it * kSyncThreads < n_raw) stage[it] = iq[b0 + tid + it * kSyncThreads];
+        } else {
+#pragma unroll
+            for (int it = 0; it < kTileIters + kHistIters; it++) {
+                const int q = tid + it * kSyncThreads;
+                const int64_t j = b0 + q;
+                const bool inside = q < n_raw && j >= 0 && j < n;
+                const cf32 v = iq[inside ? j : 0];
+                stage[it] = cf32{ inside ? v.re : 0.0f, inside ? v.im : 0.0f };
+            }
         }
 #pragma unroll
         for (int it = 0; it < kTileIters + kHistIters; it++) {
@@ -336,10 +367,14 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     float cr[R], ci[R];
     double tr = 0, ti = 0, te = 0;
     {
+        // strips start at multiples of R = 8 or 16 and the padding adds one element per 16: inside a strip the padded
+        // index advances with the sample index, so one padded base per row and immediate offsets do
         const int base = half + (nh + tid) * R;
+        const cf32* ra = raw + sync_pad<R>(base);
+        const cf32* rb = raw + sync_pad<R>(base - half);
 #pragma unroll
         for (int s = 0; s < R; s++) {
-            const cf32 a = raw[sync_pad<R>(base + s)], b = raw[sync_pad<R>(base + s - half)];
+            const cf32 a = ra[s], b = rb[s];
             cr[s] = a.re * b.re + a.im * b.im;
             ci[s] = a.im * b.re - a.re * b.im;
             const float e = 0.5f * (a.re * a.re + a.im * a.im);
@@ -349,9 +384,11 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     double hr = 0, hi = 0, he = 0; // history strip `tid` (wave 0 only: nh <= 64)
     if (tid < nh) {
         const int base = half + tid * R;
+        const cf32* ra = raw + sync_pad<R>(base);
+        const cf32* rb = raw + sync_pad<R>(base - half);
 #pragma unroll
         for (int s = 0; s < R; s++) {
-            const cf32 a = raw[sync_pad<R>(base + s)], b = raw[sync_pad<R>(base + s - half)];
+            const cf32 a = ra[s], b = rb[s];
             hr += double(a.re * b.re + a.im * b.im);
             hi += double(a.im * b.re - a.re * b.im);
             he += double(0.5f * (a.re * a.re + a.im * a.im));
@@ -359,18 +396,11 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     }
     // ---- scans (inclusive, fixed order)
     if (wid == 0) {
-        for (int o = 1; o < 64; o <<= 1) {
-            const double a = __shfl_up(hr, o), b = __shfl_up(hi, o), c = __shfl_up(he, o);
-            if (lane >= o) { hr += a; hi += b; he += c; }
-        }
+        hr = wave_scan(hr); hi = wave_scan(hi); he = wave_scan(he);
         if (lane < nh) { cp_r[lane] = hr; cp_i[lane] = hi; cp_e[lane] = he; }
         if (lane == nh - 1) { halo_tot[0] = hr; halo_tot[1] = hi; halo_tot[2] = he; }
     }
-    double xr = tr, xi = ti, xe = te;
-    for (int o = 1; o < 64; o <<= 1) {
-        const double a = __shfl_up(xr, o), b = __shfl_up(xi, o), c = __shfl_up(xe, o);
-        if (lane >= o) { xr += a; xi += b; xe += c; }
-    }
+    const double xr = wave_scan(tr), xi = wave_scan(ti), xe = wave_scan(te);
     if (lane == 63) { wave_tot[0][wid] = xr; wave_tot[1][wid] = xi; wave_tot[2][wid] = xe; }
     __syncthreads();
     {
@@ -407,10 +437,13 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     if (tid == 0 && m0 - 1 >= 0) { float num, den; metric_parts(num, den); prev0 = above(num, den); }
     unsigned flags = 0;
     const int rb_new = N + half + tid * R;      // raw index of r[m0]
+    const cf32* r_new = raw + sync_pad<R>(rb_new);
+    const cf32* r_half = raw + sync_pad<R>(rb_new - half);
+    const cf32* r_full = raw + sync_pad<R>(rb_new - N);
 #pragma unroll
     for (int s = 0; s < R; s++) {
-        const cf32 oa = raw[sync_pad<R>(rb_new + s - half)], ob = raw[sync_pad<R>(rb_new + s - N)];
-        const cf32 na = raw[sync_pad<R>(rb_new + s)];
+        const cf32 oa = r_half[s], ob = r_full[s];
+        const cf32 na = r_new[s];
         const float ocr = oa.re * ob.re + oa.im * ob.im, oci = oa.im * ob.re - oa.re * ob.im;
         const float oeh = 0.5f * (ob.re * ob.re + ob.im * ob.im);
         const float neh = 0.5f * (na.re * na.re + na.im * na.im);
@@ -428,18 +461,20 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     const int64_t m_last = min<int64_t>(m0 + R, n) - 1; // last valid output of the strip
     last_flag[tid] = (m_last >= m0) ? ((flags >> int(m_last - m0)) & 1u) : 0;
     __syncthreads();
-    bool prev = tid ? (last_flag[tid - 1] != 0) : prev0;
+    const bool prev = tid ? (last_flag[tid - 1] != 0) : prev0;
     if (m0 >= n) return;
-#pragma unroll
-    for (int s = 0; s < R; s++) {
-        const int64_t m = m0 + s;
-        if (m >= n) break;
-        const bool cur = (flags >> s) & 1u;
-        if (cur != prev && m >= m_begin) {
-            const unsigned int slot = atomicAdd(n_edges, 1u);
-            if (slot < max_edges) edges[slot] = (static_cast<unsigned long long>(m) << 1) | (cur ? 1ull : 0ull);
-        }
-        prev = cur;
+    // crossings of the strip: bit s of `trans` = flag(s) != flag(s - 1); nearly every strip has none
+    const int n_valid = int(min<int64_t>(R, n - m0));
+    const int first_valid = int(max<int64_t>(0, m_begin - m0));
+    unsigned valid = n_valid >= 32 ? 0xFFFFFFFFu : ((1u << n_valid) - 1u);
+    valid &= first_valid >= 32 ? 0u : ~((1u << first_valid) - 1u);
+    unsigned trans = (flags ^ ((flags << 1) | (prev ? 1u : 0u))) & valid;
+    while (trans) {
+        const int sidx = __ffs(int(trans)) - 1;
+        trans &= trans - 1;
+        const bool cur = (flags >> sidx) & 1u;
+        const unsigned int slot = atomicAdd(n_edges, 1u);
+        if (slot < max_edges) edges[slot] = (static_cast<unsigned long long>(m0 + sidx) << 1) | (cur ? 1ull : 0ull);
     }
 }
 
