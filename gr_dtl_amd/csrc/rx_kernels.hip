@@ -421,7 +421,8 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     const double bound = exact_ok ? 0.5 * (double(__int_as_float(int(thr_bits - 1))) + double(thr)) : 0.0;
     const bool tie_up = (thr_bits & 1u) == 0;   // a quotient exactly on the boundary rounds to the even mantissa
     auto above = [&](float num, float den) -> bool {
-        if (!WITH_METRIC && exact_ok && den > 0.0f && den < 3.0e38f && num < 3.0e38f) {
+        // num, den >= 0 (sums of squares) or NaN: one range test covers "finite and den > 0"
+        if (!WITH_METRIC && exact_ok && den > 0.0f && fmaxf(num, den) < 3.0e38f && num == num) {
             const double lhs = double(num), rhs = bound * double(den);
             return tie_up ? lhs >= rhs : lhs > rhs;
         }
