@@ -412,6 +412,9 @@ def main():
                        "samples_per_gpu": n_samples, "constellation": int(w["cnst"]), "esn0_db": w["esn0_db"],
                        "sync_threshold": w["sync_threshold"], "ldpc": "n=300 k=152, <=15 it, f64 LR-domain SPA",
                        "arith": args.arith,
+                       "operating_point": "lowest Es/N0 on a 1 dB grid at which >= 99 % of the frames are decoded with the "
+                                          "reference's default sync_threshold 0.95 (DESIGN.md 6); round 1's line ran 23 dB at "
+                                          "threshold 0.98 -- the same batch at 23 dB is in extra.other_operating_points",
                        "parallelism": "frame-batch shard per GPU (dp%d), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": "ldpc_bp_np_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
