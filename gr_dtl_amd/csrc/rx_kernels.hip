@@ -420,22 +420,28 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     const bool exact_ok = thr > 1.17549435e-38f && thr < 3.0e38f;
     const double bound = exact_ok ? 0.5 * (double(__int_as_float(int(thr_bits - 1))) + double(thr)) : 0.0;
     const bool tie_up = (thr_bits & 1u) == 0;   // a quotient exactly on the boundary rounds to the even mantissa
-    auto above = [&](float num, float den) -> bool {
+    // A window of zeros: the reference's FIR sums are exactly 0 there and 0/0 = NaN is never above the threshold.  The
+    // f64 sums of a tile can keep a rounding residue of what the tile held before (<= 2^-40 of the tile's energy after
+    // 2 * (tile + history) additions): window energy at or below that is indistinguishable from zero and treated as zero.
+    const float e_tile = float(cp_e[nS - 1]);
+    const float e_floor = e_tile < 3.0e38f ? e_tile * 0x1p-38f : 0.0f;  // NaN / inf samples in the tile: no floor
+    auto above = [&](float num, float den, float E) -> bool {
         // num, den >= 0 (sums of squares) or NaN: one range test covers "finite and den > 0"
-        if (!WITH_METRIC && exact_ok && den > 0.0f && fmaxf(num, den) < 3.0e38f && num == num) {
+        if (!WITH_METRIC && exact_ok && E > e_floor && den > 0.0f && fmaxf(num, den) < 3.0e38f && num == num) {
             const double lhs = double(num), rhs = bound * double(den);
             return tie_up ? lhs >= rhs : lhs > rhs;
         }
-        return num / den >= thr;
+        return E > e_floor && num / den >= thr;
     };
-    auto metric_parts = [&](float& num, float& den) {
-        const float Pr = float(-Wr), Pi = float(-Wi), E = float(We);
+    auto metric_parts = [&](float& num, float& den, float& E) {
+        const float Pr = float(-Wr), Pi = float(-Wi);
+        E = float(We);
         num = Pr * Pr + Pi * Pi;
         den = E * E;
     };
     const int64_t m0 = t0 + int64_t(tid) * R;
     bool prev0 = false;                         // flag of sample m0 - 1 as this tile sees it (lane 0 of the tile uses it)
-    if (tid == 0 && m0 - 1 >= 0) { float num, den; metric_parts(num, den); prev0 = above(num, den); }
+    if (tid == 0 && m0 - 1 >= 0) { float num, den, E; metric_parts(num, den, E); prev0 = above(num, den, E); }
     unsigned flags = 0;
     const int rb_new = N + half + tid * R;      // raw index of r[m0]
     const cf32* r_new = raw + sync_pad<R>(rb_new);
@@ -451,13 +457,13 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         Wr = (Wr + double(cr[s])) - double(ocr);
         Wi = (Wi + double(ci[s])) - double(oci);
         We = (We + double(neh)) - double(oeh);
-        float num, den;
-        metric_parts(num, den);
+        float num, den, E;
+        metric_parts(num, den, E);
         if (WITH_METRIC) {
             const int64_t m = m0 + s;
-            if (m >= m_begin && m < n) metric_out[m - m_begin] = num / den;
+            if (m >= m_begin && m < n) metric_out[m - m_begin] = E > e_floor ? num / den : __int_as_float(0x7fc00000);
         }
-        if (above(num, den)) flags |= 1u << s;
+        if (above(num, den, E)) flags |= 1u << s;
     }
     const int64_t m_last = min<int64_t>(m0 + R, n) - 1; // last valid output of the strip
     last_flag[tid] = (m_last >= m0) ? ((flags >> int(m_last - m0)) & 1u) : 0;

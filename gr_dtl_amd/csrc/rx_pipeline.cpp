@@ -1145,8 +1145,11 @@ int Receiver::stage_triggers(Call& c)
     {
         size_t ri = 0; // number of segments starting <= tpos (both lists are sorted)
         const int64_t need = int64_t(final ? hdr_syms : hdr_syms + L) * P;
+        // ... and the raw trigger list must be final up to the frame's last sample: a trigger found by a later call
+        // (its plateau is still open at the end of this one) starts a new oscillator segment inside the frame
+        const int64_t ready = final ? E : std::min(E, produced);
         for (int64_t tpos : ss.pending_fixed) {
-            if (tpos + need > E) break;
+            if (tpos + need > ready) break;
             while (ri < ss.segs.size() && ss.segs[ri].start <= tpos) ri++;
             Candidate c{};
             c.trigger = tpos - A;

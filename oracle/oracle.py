@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_LIB_PATH = os.environ.get("DTL_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")  # override: a sanitizer build
 
 
 def build(force=False):

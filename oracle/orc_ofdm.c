@@ -157,25 +157,36 @@ void orc_sync_sc(const orc_cfg* cfg, const orc_c32* iq, long n, float* metric_ou
     /* delay(N/2) -> conjugate -> multiply_cc -> fir_filter_ccf(N/2 taps of -1)   [P]
      * complex_to_mag_squared -> fir_filter_fff(N taps of 0.5) -> multiply_ff(x,x) [E^2]
      * metric = |P|^2 / E^2 ; angle = arg(P).  Window sums are accumulated in double and
-     * rounded to float once (the reference's float FIR order is SIMD-dependent). */
+     * rounded to float once (the reference's float FIR order is SIMD-dependent).  A FIR over a window
+     * of zeros is exactly zero (-> 0/0 = NaN, never above the threshold): a running sum would keep the
+     * rounding residue of everything that went before, so the sums are cleared whenever their window
+     * holds no non-zero term. */
     double pr = 0, pi = 0, en = 0;
+    long nz_c = 0, nz_e = 0;
     for (long i = 0; i < n; i++) {
         cf cur = to_cf(iq[i]);
         cf dly = (i >= half) ? to_cf(iq[i - half]) : 0;
         cf c = cur * conjf(dly);
         pr += crealf(c); pi += cimagf(c);
+        nz_c += (crealf(c) != 0.0f || cimagf(c) != 0.0f);
         if (i >= half) {
             cf co = to_cf(iq[i - half]);
             cf dlo = (i - half >= half) ? to_cf(iq[i - 2 * half]) : 0;
             cf cold = co * conjf(dlo);
             pr -= crealf(cold); pi -= cimagf(cold);
+            nz_c -= (crealf(cold) != 0.0f || cimagf(cold) != 0.0f);
         }
         float e = crealf(cur) * crealf(cur) + cimagf(cur) * cimagf(cur);
         en += 0.5f * e;
+        nz_e += (0.5f * e != 0.0f);
         if (i >= N) {
             cf o = to_cf(iq[i - N]);
-            en -= 0.5f * (crealf(o) * crealf(o) + cimagf(o) * cimagf(o));
+            float eo = 0.5f * (crealf(o) * crealf(o) + cimagf(o) * cimagf(o));
+            en -= eo;
+            nz_e -= (eo != 0.0f);
         }
+        if (nz_c == 0) pr = pi = 0;
+        if (nz_e == 0) en = 0;
         float Pr = (float)(-pr), Pi = (float)(-pi), E = (float)en;
         float num = Pr * Pr + Pi * Pi;
         metric[i] = num / (E * E);

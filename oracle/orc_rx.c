@@ -60,8 +60,9 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
 
     orc_c32* sym_t = (orc_c32*)malloc((size_t)N * (hdr_syms + L) * sizeof(orc_c32));
     orc_c32* sym_f = (orc_c32*)malloc((size_t)N * (hdr_syms + L) * sizeof(orc_c32));
-    orc_c32* hard = (orc_c32*)malloc((size_t)N * L * sizeof(orc_c32));
-    orc_c32* soft = (orc_c32*)malloc((size_t)N * L * sizeof(orc_c32));
+    const int eq_syms = L > h ? L : h;  /* the header symbols go through the same buffers */
+    orc_c32* hard = (orc_c32*)malloc((size_t)N * eq_syms * sizeof(orc_c32));
+    orc_c32* soft = (orc_c32*)malloc((size_t)N * eq_syms * sizeof(orc_c32));
     orc_c32* ser = (orc_c32*)malloc((size_t)(cap + N) * sizeof(orc_c32));
     orc_c32* taps = (orc_c32*)malloc((size_t)N * sizeof(orc_c32));
     float* llr = (float*)malloc((size_t)cap * 4 * sizeof(float));

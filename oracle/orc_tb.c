@@ -225,7 +225,12 @@ static void tb_decode(orc_tbdec* d, int tb_len, int* avg_it)
             d->full[(long)i * n + ncheck + j] = (rcv_idx < d->rcv_size) ? d->rcv[rcv_idx] : 0.0f;
         int nit = 0;
         orc_ldpc_decode_arith(d->code, &d->full[(long)i * n], d->max_it, d->bp_sigma, d->arith, cw_out, &nit);
-        memcpy(&d->data[d_idx], cw_out, k_); /* reference copies k bits; later codewords overwrite the tail */
+        /* the reference decodes k bits straight into its data buffer at d_idx and advances by k_: for k_ < k the
+         * next codeword overwrites the tail; for k_ > k (a block flushed with the next frame's constellation,
+         * tb_decoder.cc:99-103) bits d_idx+k .. d_idx+k_ keep what an earlier block left there.  Restated as 0:
+         * the block's CRC-32 fails either way */
+        memcpy(&d->data[d_idx], cw_out, k_ < k ? k_ : k);
+        if (k_ > k) memset(&d->data[d_idx + k], 0, k_ - k);
         d_idx += k_;
         sum_it += nit;
     }

@@ -1,0 +1,74 @@
+"""Randomised differential test: the HIP chain against the oracle on scenarios drawn from the whole parameter space
+(FFT length, frame length, constellation sequence, Es/N0, carrier frequency offset, sync threshold, frame_detect_bb
+on / off, FEC code, idle gaps, stream cut short), every stage compared as in test_rx_gpu.  Fixed seeds: a failure
+reproduces."""
+import numpy as np
+import pytest
+
+from helpers import ES, make_pair
+from test_rx_gpu import _compare, _run_both
+from test_stream_gpu import _assert_same, _feed_all
+
+CODES = ("n_0300_k_0152_gap_03.alist", "n_0100_k_0023_gap_10.alist", "n_0100_k_0027_gap_04.alist")
+
+
+def _scenario(oracle, dtl, rng):
+    fft_len = int(rng.choice([64, 64, 128, 256]))
+    frame_length = int(rng.integers(1, 21)) if fft_len == 64 else int(rng.integers(2, 13))
+    fec = rng.choice([None, *CODES]) if fft_len == 64 else rng.choice(CODES)
+    thr = float(rng.choice([0.95, 0.95, 0.9, 0.97]))
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, fec=None if fec is None else str(fec),
+                                 sync_threshold=thr, use_sync_correct=bool(rng.integers(0, 2)),
+                                 llr_dist_mode=int(rng.integers(0, 2)), arith=str(rng.choice(["gr_exact", "gr_exact", "fast"])))
+    n_seg = int(rng.integers(1, 4))
+    parts, frame_no, tb_no = [], 0, 0
+    worst = 0.0
+    gap = int(rng.choice([0, 0, 0, 7, 64]))
+    for _ in range(n_seg):
+        cnst = int(rng.integers(1, 5))
+        per_frame = max(ocfg.frame_capacity * cnst // 8, 8)
+        user = rng.integers(0, 256, int(rng.integers(1, 6 * per_frame)), dtype=np.uint8)
+        if code is not None and (max(1, 1 + (ocfg.frame_capacity * cnst // 8 * 8) // code.n) * code.k) // 8 <= 4:
+            cnst = 4                                        # this code's transport block holds no payload at this frame size
+        if code is not None:
+            syms, hdrs = oracle.fec_frames_build(code, 1, cnst, ocfg.frame_capacity, user, first_frame_no=frame_no)
+        else:
+            syms, hdrs = oracle.nofec_frames_build(cnst, ocfg.frame_capacity, user, first_frame_no=frame_no)
+        frame_no = (frame_no + len(hdrs)) & 0xFFF
+        iq = oracle.tx_frames(ocfg, syms, hdrs)
+        if gap:
+            iq = np.concatenate([iq, np.zeros((iq.shape[0], gap), np.complex64)], axis=1)
+        parts.append(iq.reshape(-1))
+        worst = max(worst, ES[cnst] / {1: 1.0, 2: 1.0, 3: 3.0, 4: 6.0}[cnst])
+    x = np.concatenate([np.zeros(int(rng.integers(0, 300)), np.complex64)] + parts +
+                       [np.zeros(int(rng.integers(0, ocfg.frame_samples + 1)), np.complex64)])
+    esn0 = float(rng.uniform(17.0, 30.0))
+    nv = fft_len * 1.0 / 10 ** (esn0 / 10)
+    if rng.integers(0, 4) == 0:
+        nv = 0.0                                                                   # a noise-free scenario now and then
+    eps = float(rng.choice([0.0, 0.0, rng.uniform(-0.45, 0.45), rng.uniform(-3.0, 3.0)]))
+    if eps:
+        n = np.arange(x.size, dtype=np.float64)
+        x = (x * np.exp(2j * np.pi * eps * n / fft_len)).astype(np.complex64)
+    if nv:
+        x = (x + (rng.normal(0, np.sqrt(nv / 2), x.size) + 1j * rng.normal(0, np.sqrt(nv / 2), x.size))).astype(np.complex64)
+    if rng.integers(0, 5) == 0:
+        x = x[:int(x.size * rng.uniform(0.5, 0.99))]                               # the capture ends inside a frame
+    return pcfg, ocfg, code, np.ascontiguousarray(x), dict(fft_len=fft_len, frame_length=frame_length, fec=fec, thr=thr,
+                                                           gap=gap, esn0=esn0, eps=eps, n=x.size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(400)))
+def test_random_scenario_matches_oracle(oracle, dtl, cuda, seed):
+    rng = np.random.default_rng(9000 + seed)
+    pcfg, ocfg, code, x, info = _scenario(oracle, dtl, rng)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, max_frames=x.size // 64 + 16)
+    _compare(rx, res, ref, ocfg, code is not None)
+    # the same stream cut at random points and fed call by call: bit-identical to the batch call
+    import torch
+    xt = torch.from_numpy(x).to(cuda)
+    n_cuts = int(rng.choice([1, 3, 12, 40]))
+    cuts = sorted(set(int(c) for c in rng.integers(1, max(x.size, 2), n_cuts))) if x.size > 1 else []
+    rx2 = dtl.ofdm_receiver(pcfg)
+    _assert_same(rx2.work(xt), _feed_all(dtl.ofdm_receiver(pcfg), xt, cuts))

@@ -22,12 +22,12 @@ def _close(got, want, rtol=RTOL, atol=0.0, what=""):
     assert not bad.any(), (what, int(bad.sum()), float(np.nanmax(np.where(bad, err / np.maximum(np.abs(want), 1e-30), 0))))
 
 
-def _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, want_llr=True):
+def _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, want_llr=True, max_frames=None):
     import torch
     rx = dtl.ofdm_receiver(pcfg)
     want = ("eq_hard", "eq_soft", "soft_syms", "hdr_bits", "llr", "taps", "cw")
     res = rx.work(torch.from_numpy(x).to(cuda), want=want)
-    ref = oracle.rx_stream(ocfg, code, x, feedback=oracle_feedback(oracle, pcfg, rx),
+    ref = oracle.rx_stream(ocfg, code, x, feedback=oracle_feedback(oracle, pcfg, rx), max_frames=max_frames,
                            want=("frames", "trig", "angle", "eq_hard", "eq_soft", "soft_syms", "llr", "hdr_bits", "taps"))
     return rx, res, ref
 
@@ -63,11 +63,8 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
     used = occ_mask | pil_mask
     frames = res.frames
     eq_hard = res.eq_hard.cpu().numpy() if res.eq_hard is not None else None
-    eq_soft = res.eq_soft.cpu().numpy()
-    soft_syms = res.soft_syms.cpu().numpy()
-    llr = res.llr.cpu().numpy()
-    taps = res.taps.cpu().numpy()
-    hdr_bits = res.hdr_bits.cpu().numpy()
+    eq_soft, soft_syms, llr, taps, hdr_bits = (None if a is None else a.cpu().numpy()      # None: nothing was found
+                                               for a in (res.eq_soft, res.soft_syms, res.llr, res.taps, res.hdr_bits))
     for i, rf in enumerate(ref["frames"]):
         f = frames[i]
         assert f["trigger"] == rf["trigger"] and f["header_ok"] == rf["header_ok"], i
