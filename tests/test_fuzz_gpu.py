@@ -1,7 +1,9 @@
 """Randomised differential test: the HIP chain against the oracle on scenarios drawn from the whole parameter space
 (FFT length, frame length, constellation sequence, Es/N0, carrier frequency offset, sync threshold, frame_detect_bb
 on / off, FEC code, idle gaps, stream cut short), every stage compared as in test_rx_gpu.  Fixed seeds: a failure
-reproduces."""
+reproduces.  DTL_FUZZ_FIRST / DTL_FUZZ_LAST widen the sweep (default: seeds 0 .. 399, ~15 s)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,6 +23,13 @@ def _scenario(oracle, dtl, rng):
                                  sync_threshold=thr, use_sync_correct=bool(rng.integers(0, 2)),
                                  llr_dist_mode=int(rng.integers(0, 2)), arith=str(rng.choice(["gr_exact", "gr_exact", "fast"])))
     n_seg = int(rng.integers(1, 4))
+    impair = bool(rng.integers(0, 2))
+    channel = None
+    if rng.integers(0, 3) == 0:                                      # a short multipath channel inside the cyclic prefix
+        taps = int(rng.integers(2, max(3, pcfg.cp_len // 2)))
+        channel = (rng.normal(0, 1, taps) + 1j * rng.normal(0, 1, taps)) * np.exp(-0.7 * np.arange(taps))
+        channel[0] = 1.0
+        channel = (channel / np.sqrt(np.sum(np.abs(channel) ** 2))).astype(np.complex64)
     parts, frame_no, tb_no = [], 0, 0
     worst = 0.0
     gap = int(rng.choice([0, 0, 0, 7, 64]))
@@ -38,10 +47,24 @@ def _scenario(oracle, dtl, rng):
         iq = oracle.tx_frames(ocfg, syms, hdrs)
         if gap:
             iq = np.concatenate([iq, np.zeros((iq.shape[0], gap), np.complex64)], axis=1)
-        parts.append(iq.reshape(-1))
+        rows = [r for r in iq]
+        if impair:
+            for j in range(len(rows)):
+                u = rng.integers(0, 24)
+                if u == 0:
+                    rows[j] = np.zeros_like(rows[j])                 # a frame that never arrives (idle air)
+                elif u == 1:
+                    rows[j] = rows[j][:-1]                           # the transmitter's clock slips one sample
+                elif u == 2:
+                    rows[j] = np.concatenate([rows[j], rows[j][-1:]])
+                elif u == 3 and len(rows) > 2:
+                    rows[j] = rows[j][:0]                            # a frame cut out of the stream entirely
+        parts.append(np.concatenate(rows) if rows else np.zeros(0, np.complex64))
         worst = max(worst, ES[cnst] / {1: 1.0, 2: 1.0, 3: 3.0, 4: 6.0}[cnst])
     x = np.concatenate([np.zeros(int(rng.integers(0, 300)), np.complex64)] + parts +
                        [np.zeros(int(rng.integers(0, ocfg.frame_samples + 1)), np.complex64)])
+    if channel is not None:
+        x = np.convolve(x, channel).astype(np.complex64)[:x.size]
     esn0 = float(rng.uniform(17.0, 30.0))
     nv = fft_len * 1.0 / 10 ** (esn0 / 10)
     if rng.integers(0, 4) == 0:
@@ -55,11 +78,12 @@ def _scenario(oracle, dtl, rng):
     if rng.integers(0, 5) == 0:
         x = x[:int(x.size * rng.uniform(0.5, 0.99))]                               # the capture ends inside a frame
     return pcfg, ocfg, code, np.ascontiguousarray(x), dict(fft_len=fft_len, frame_length=frame_length, fec=fec, thr=thr,
-                                                           gap=gap, esn0=esn0, eps=eps, n=x.size)
+                                                           gap=gap, esn0=esn0, eps=eps, n=x.size, impair=impair,
+                                                           channel=None if channel is None else channel.size)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(400)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("DTL_FUZZ_FIRST", "0")), int(os.environ.get("DTL_FUZZ_LAST", "400")))))
 def test_random_scenario_matches_oracle(oracle, dtl, cuda, seed):
     rng = np.random.default_rng(9000 + seed)
     pcfg, ocfg, code, x, info = _scenario(oracle, dtl, rng)
