@@ -163,6 +163,7 @@ struct orc_tbdec {
     long buf_idx;
     int have_info, info_tb_payload;          /* d_fec_info (only the fields decode() uses)    */
     uint8_t* crc_buffer;
+    long data_cap;                           /* bits d->data / d->crc_buffer can hold (vectors in the reference) */
     long crc_ok_count, crc_fail_count;
 };
 
@@ -179,8 +180,9 @@ orc_tbdec* orc_tbdec_new(const orc_ldpc* c, int frame_capacity, int max_bps, int
     d->rcv_cap = 2L * max_tb_len;                              /* tb_decoder.cc:24-27 */
     d->rcv = (float*)calloc(d->rcv_cap + 64, sizeof(float));
     d->full = (float*)calloc(2L * max_tb_len + 64, sizeof(float));
-    d->data = (uint8_t*)calloc(2L * max_tb_len + 64, 1);
-    d->crc_buffer = (uint8_t*)calloc((size_t)k * ncws / 8 + 16, 1);
+    d->data_cap = 2L * max_tb_len;
+    d->data = (uint8_t*)calloc(d->data_cap + k + 64, 1);
+    d->crc_buffer = (uint8_t*)calloc(d->data_cap / 8 + 16, 1);
     d->tb_number = -1;
     return d;
 }
@@ -208,6 +210,11 @@ static void tb_decode(orc_tbdec* d, int tb_len, int* avg_it)
     const int n = orc_ldpc_n(d->code), k = orc_ldpc_k(d->code), ncheck = n - k;
     int payload_len = d->info_tb_payload;
     d->data_len = d->info_tb_payload;
+    if (d->info_tb_payload > d->data_cap) { /* d_data_buffer.resize(): a header may announce any 16-bit length */
+        d->data_cap = d->info_tb_payload;
+        d->data = (uint8_t*)realloc(d->data, d->data_cap + k + 64);
+        d->crc_buffer = (uint8_t*)realloc(d->crc_buffer, d->data_cap / 8 + 16);
+    }
     for (long i = 0; i < (long)tb_len * n; i++) d->full[i] = -15.0f; /* SHORTENED_VALUE */
     long rcv_idx = 0;
     int d_idx = 0, sum_it = 0;
@@ -221,8 +228,10 @@ static void tb_decode(orc_tbdec* d, int tb_len, int* avg_it)
          * received carry no information": value 0. */
         for (int j = 0; j < ncheck; j++, rcv_idx++)
             d->full[(long)i * n + j] = (rcv_idx < d->rcv_size) ? d->rcv[rcv_idx] : 0.0f;
+        /* k_ > k (see below): the reference's copy runs on into the next codeword's slots, which that codeword's
+         * own copy then overwrites (k_ - k <= ncheck + its k_) -- never seen by a decode, so not stored here */
         for (int j = 0; j < k_; j++, rcv_idx++)
-            d->full[(long)i * n + ncheck + j] = (rcv_idx < d->rcv_size) ? d->rcv[rcv_idx] : 0.0f;
+            if (j < k) d->full[(long)i * n + ncheck + j] = (rcv_idx < d->rcv_size) ? d->rcv[rcv_idx] : 0.0f;
         int nit = 0;
         orc_ldpc_decode_arith(d->code, &d->full[(long)i * n], d->max_it, d->bp_sigma, d->arith, cw_out, &nit);
         /* the reference decodes k bits straight into its data buffer at d_idx and advances by k_: for k_ < k the

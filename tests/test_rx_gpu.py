@@ -83,8 +83,11 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
         np.testing.assert_array_equal(eq_hard[pi][:, used], h_ref[:, used])   # sliced symbols: exact
         _close(eq_soft[pi], s_ref, atol=2e-6, what="eq_soft frame %d" % i)
         _count_exact("soft", eq_soft[pi], s_ref)
-        _close(f["snr_db"], rf["snr_db"], rtol=1e-6, atol=1e-6, what="snr")
-        _close(f["noise"], rf["noise_lin"], rtol=1e-5, what="noise")
+        if rf["snr_db"] < 100.0:
+            _close(f["snr_db"], rf["snr_db"], rtol=1e-6, atol=1e-6, what="snr")
+            _close(f["noise"], rf["noise_lin"], rtol=1e-5, what="noise")
+        else:   # a noise-free stream: the estimator measures float rounding -- one ulp in one of a few pilots moves it by dBs
+            assert f["snr_db"] > 100.0
         assert (f["feedback_cnst"], f["feedback_fec"], f["lost_frames"]) == (rf["fb_cnst"], rf["fb_fec"], rf["lost_frames"])
         if rf["hdr"]["payload_len"]:
             ns = min(rf["n_payload_syms"], ocfg.frame_capacity)
