@@ -38,6 +38,38 @@ __device__ __forceinline__ float dm_exp(float x)
     return (x != x) ? x : res;
 }
 
+// exp(x) in double with the same construction (k = rint(x log2e), r = x - k ln2 with fdlibm's hi/lo split, Taylor
+// polynomial of degree 13 in Horner form, 2^k applied last); < 1 ulp.  The LDPC decoder's channel likelihood ratios use
+// it instead of the library exp, whose last bit is the library's own (ocml and glibc differ at x = 40): the CPU oracle
+// executes the same sequence (oracle/orc_math.h orc_exp).
+__device__ __forceinline__ double dm_exp64(double x)
+{
+    const double kd = rint(x * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(-kd, 0x1.62e42fee00000p-1, x);
+    r = __builtin_fma(-kd, 0x1.a39ef35793c76p-33, r);
+    double p = 0x1.6124613a86d09p-33;
+    p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);
+    p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);
+    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
+    p = __builtin_fma(p, r, 0x1.0000000000000p-1);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    // |x| <= 746 on this path: |k| <= 1077, the two-step scaling keeps both factors normal; the first product is exact
+    const int k = int(fmin(fmax(kd, -1100.0), 1100.0));
+    const int k1 = k / 2, k2 = k - k1;
+    double res = (p * __longlong_as_double((long long)(k1 + 1023) << 52)) * __longlong_as_double((long long)(k2 + 1023) << 52);
+    res = (x > 710.0) ? __longlong_as_double(0x7ff0000000000000LL) : res;
+    res = (x < -746.0) ? 0.0 : res;
+    return (x != x) ? x : res;
+}
+
 // a / b for operands that need none of v_div_scale / v_div_fixup's range handling (no scaling, no
 // special values): the refinement sequence the compiler emits for an IEEE single division, minus those
 // two steps -- same bits, 8 instructions instead of 11 and no VCC hazard.  Only used by dm_log, where

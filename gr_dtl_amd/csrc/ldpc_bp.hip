@@ -16,6 +16,7 @@
 //  * a persistent grid strides over the codeword batch (codewords have 0..max_it iterations,
 //    the stride averages the imbalance); 16 single-wave workgroups fit a CU's 160 KB LDS.
 #include "ldpc_bp.h"
+#include "dtl_math.h"
 
 #include <type_traits>
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const floa
             // awgn_bp::rx_lr_calc
             // (float expression, exp of the float-rounded argument; rx does not overlap ybuf)
             const float s2 = sigma * sigma;
-            for (int v = lane; v < t.n; v += kWave) rx[v] = exp(double((-1 * 2 * ybuf[v]) / s2));
+            for (int v = lane; v < t.n; v += kWave) rx[v] = dm_exp64(double((-1 * 2 * ybuf[v]) / s2));
             __syncthreads(); // ybuf (aliasing msg) is dead from here
             // awgn_bp::spa_initialize
             for (int e = lane; e < t.n_edges; e += kWave) msg[e] = rx[t.edge_var[e]];
@@ -486,9 +487,11 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             bool wild = false;                            // a channel exponent outside the tame range (or NaN)
             for (int v = lane; v < t.n; v += kWave) {
                 float arg = (-1 * 2 * ybuf[v]) / s2;
-                if (FAST) arg = fminf(fmaxf(arg, -kFastLlrMax), kFastLlrMax);
+                // written as comparisons: NaN (no ordering) takes the last branch -- the compiler may turn an fmin/fmax clamp
+                // into a median instruction whose NaN result differs
+                if (FAST) arg = arg > kFastLlrMax ? kFastLlrMax : (arg >= -kFastLlrMax ? arg : -kFastLlrMax);
                 wild |= !(fabsf(arg) <= kTameArgMax);
-                rx[v] = exp(double(arg));
+                rx[v] = dm_exp64(double(arg));
             }
             if (lane == 0) rx[t.n] = 0.0;
             wave_sync();

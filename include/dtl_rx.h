@@ -59,7 +59,7 @@ int dtl_device_count(void);
 typedef struct dtl_ldpc dtl_ldpc;
 
 /* ldpc_dec::ldpc_dec(alist_fname, max_it): parse the alist, reduce H to systematic form
- * (cldpc), build device tables.  max_iterations: 15 in the reference (ldpc_dec.cc:27).
+ * (cldpc), build device tables.  max_iterations: 15 in the reference (ldpc_dec.cc:27); <= 0 selects that default.
  * sigma: awgn_bp's noise sigma, which gr-dtl never sets; pass 0 for the documented default
  * sqrt(2) (rx likelihood ratio = exp(llr)). */
 int dtl_ldpc_create(const char* alist_path, int max_iterations, float sigma, dtl_ldpc** out);

@@ -7,6 +7,7 @@
  *  -- "parity unpinned" for the permutation and for every BP iteration.
  */
 #include "oracle.h"
+#include "orc_math.h"
 
 #include <math.h>
 #include <pthread.h>
@@ -201,7 +202,7 @@ int orc_ldpc_decode(const orc_ldpc* c, const float* llr, int max_it, float sigma
         /* rx_lr_calc: float expression, exp evaluated on the float-rounded argument */
         for (int i = 0; i < N; i++) {
             float arg = (-1 * 2 * y[i]) / (sigma * sigma);
-            rx_lr[i] = exp((double)arg);
+            rx_lr[i] = orc_exp((double)arg);
         }
         /* spa_initialize */
         for (int e = 0; e < E; e++) Q[e] = rx_lr[c->edge_var[e]];
@@ -250,8 +251,9 @@ int orc_ldpc_decode(const orc_ldpc* c, const float* llr, int max_it, float sigma
  * NaN, whose decision is 0 whatever was sent -- its error floor): channel LLR clamped to +-40, check-node
  * products to +-(1 - 2^-20) (check-to-variable ratios in [2^-21, 2^21], LLR within +-14.6: the clipping also
  * helps in the waterfall).  Variable-to-check ratios then stay below 2^121 for column weights <= 4 and a row's
- * product of (1 + Q) below 2^968 for row weights <= 8 (the product's kernel limits).  fmin/fmax return the
- * non-NaN operand.
+ * product of (1 + Q) below 2^968 for row weights <= 8 (the product's kernel limits).  A NaN soft bit is taken as
+ * -max (what fmin(fmax()) of the C library returns; written as comparisons so that no compiler substitutes a clamp
+ * instruction with another NaN rule); fmin/fmax on the products return the non-NaN operand.
  * ------------------------------------------------------------------------------------------- */
 #define ORC_FAST_LLR_MAX 40.0f
 #define ORC_FAST_P_MAX (1.0 - 0x1p-20)
@@ -286,8 +288,8 @@ int orc_ldpc_decode_fast(const orc_ldpc* c, const float* llr, int max_it, float 
         double* R = (double*)malloc(E * sizeof(double));
         for (int i = 0; i < N; i++) {
             float arg = (-1 * 2 * y[i]) / (sigma * sigma);
-            arg = fminf(fmaxf(arg, -ORC_FAST_LLR_MAX), ORC_FAST_LLR_MAX);
-            rx_lr[i] = exp((double)arg);
+            arg = arg > ORC_FAST_LLR_MAX ? ORC_FAST_LLR_MAX : (arg >= -ORC_FAST_LLR_MAX ? arg : -ORC_FAST_LLR_MAX); /* NaN -> -max */
+            rx_lr[i] = orc_exp((double)arg);
         }
         for (int e = 0; e < E; e++) Q[e] = rx_lr[c->edge_var[e]];
         while (*nit < max_it) {

@@ -44,6 +44,42 @@ static inline float orc_expf(float x)
     return (p * s1) * s2;
 }
 
+/* exp(x) in double, same construction: k = rint(x*log2e); r = x - k*ln2 (fdlibm's hi/lo split: k*ln2_hi is exact);
+ * Taylor polynomial of degree 13 (|r| <= 0.347: truncation 2^-57) in Horner form, fused multiply-adds written out;
+ * two-step scaling by 2^k (the first product is exact, the second rounds once -- also into the denormals).
+ * < 1 ulp.  The decoder's channel likelihood ratios (awgn_bp.cc: exp of the scaled soft bit) go through this instead
+ * of the C library's exp, whose last bit differs between libraries (glibc / the GPU's ocml differ at x = 40). */
+#define ORC_FMA64(a, b, c) __builtin_fma((a), (b), (c))
+static inline double orc_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 710.0) return (double)INFINITY;
+    if (x < -746.0) return 0.0;
+    double kd = rint(x * 0x1.71547652b82fep+0);
+    int k = (int)kd;
+    double r = ORC_FMA64(-kd, 0x1.62e42fee00000p-1, x);
+    r = ORC_FMA64(-kd, 0x1.a39ef35793c76p-33, r);
+    double p = 0x1.6124613a86d09p-33;
+    p = ORC_FMA64(p, r, 0x1.1eed8eff8d898p-29);
+    p = ORC_FMA64(p, r, 0x1.ae64567f544e4p-26);
+    p = ORC_FMA64(p, r, 0x1.27e4fb7789f5cp-22);
+    p = ORC_FMA64(p, r, 0x1.71de3a556c734p-19);
+    p = ORC_FMA64(p, r, 0x1.a01a01a01a01ap-16);
+    p = ORC_FMA64(p, r, 0x1.a01a01a01a01ap-13);
+    p = ORC_FMA64(p, r, 0x1.6c16c16c16c17p-10);
+    p = ORC_FMA64(p, r, 0x1.1111111111111p-7);
+    p = ORC_FMA64(p, r, 0x1.5555555555555p-5);
+    p = ORC_FMA64(p, r, 0x1.5555555555555p-3);
+    p = ORC_FMA64(p, r, 0x1.0000000000000p-1);
+    p = ORC_FMA64(p, r, 1.0);
+    p = ORC_FMA64(p, r, 1.0);
+    int k1 = k / 2, k2 = k - k1; /* |k1|, |k2| <= 538: both scale factors are normal numbers */
+    uint64_t b1 = (uint64_t)(k1 + 1023) << 52, b2 = (uint64_t)(k2 + 1023) << 52;
+    double s1, s2;
+    memcpy(&s1, &b1, 8); memcpy(&s2, &b2, 8);
+    return (p * s1) * s2;
+}
+
 /* log(x), x >= 0: fdlibm e_logf kernel */
 static inline float orc_logf(float x)
 {

@@ -101,3 +101,78 @@ def test_random_scenario_matches_oracle(oracle, dtl, cuda, seed):
         np.testing.assert_array_equal(streamed[3], batch.raw_triggers)
         return
     _assert_same(batch, streamed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(150)))
+def test_random_tx_matches_oracle(oracle, dtl, cuda, seed):
+    """The batched transmitter against the oracle's: framing, header fields and on-air samples bit for bit."""
+    import torch
+    from gr_dtl_amd.ofdm_transmitter import ofdm_transmitter
+    rng = np.random.default_rng(77000 + seed)
+    fft_len = int(rng.choice([64, 64, 128, 256, 512]))
+    frame_length = int(rng.integers(1, 21)) if fft_len == 64 else int(rng.integers(2, 9))
+    fec = rng.choice([None, *CODES])
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, fec=None if fec is None else str(fec))
+    cnst = int(rng.integers(1, 5))
+    if code is not None and (max(1, 1 + (ocfg.frame_capacity * cnst // 8 * 8) // code.n) * code.k) // 8 <= 4:
+        cnst = 4
+    per_frame = max(ocfg.frame_capacity * cnst // 8, 8)
+    user = rng.integers(0, 256, int(rng.choice([1, 2, per_frame - 1, per_frame, per_frame + 1, int(rng.integers(1, 12 * per_frame))])),
+                        dtype=np.uint8)
+    first = int(rng.integers(0, 4096))
+    if code is not None:
+        ref_syms, ref_hdrs = oracle.fec_frames_build(code, 1, cnst, ocfg.frame_capacity, user, first_frame_no=first)
+    else:
+        ref_syms, ref_hdrs = oracle.nofec_frames_build(cnst, ocfg.frame_capacity, user, first_frame_no=first)
+    ref_iq = oracle.tx_frames(ocfg, ref_syms, ref_hdrs)
+    tx = ofdm_transmitter(pcfg)
+    args = (cnst, "fec_1") if code is not None else (cnst,)
+    iq, hdrs, syms = tx.work_device(torch.from_numpy(user).to(cuda), *args, first_frame_no=first, want_syms=True)
+    assert len(hdrs) == len(ref_hdrs)
+    keys = ("payload_len", "frame_no", "cnst", "fb_cnst") + (("tb_no", "fec_fb", "tb_offset", "fec", "tb_payload") if code is not None else ())
+    for k in keys:
+        np.testing.assert_array_equal(hdrs[k], [h[k] for h in ref_hdrs], err_msg=k)
+    np.testing.assert_array_equal(syms.cpu().numpy(), ref_syms)
+    got = np.ascontiguousarray(iq.cpu().numpy())
+    assert got.shape == ref_iq.shape
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref_iq).view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(120)))
+def test_random_ldpc_inputs_match_oracle(oracle, dtl, cuda, seed):
+    """The belief-propagation decoder alone on soft bits no demapper would produce: random scale, sign errors, runs of
+    shortened positions, +-inf, NaN, zeros, denormals, exponents near the "tame" bound of the shortened division
+    sequence (|llr| ~ 500 ln 2), any iteration limit; bits and iteration counts exact in both arithmetics."""
+    import torch
+    from conftest import CODES as CODE_DIR
+    rng = np.random.default_rng(31000 + seed)
+    alist = os.path.join(CODE_DIR, str(rng.choice(CODES)))
+    code = oracle.Ldpc(alist)
+    ncw = int(rng.choice([1, 2, 63, 64, 65, 257, int(rng.integers(1, 6000))]))
+    data = rng.integers(0, 2, (ncw, code.k)).astype(np.uint8)
+    cws = np.stack([code.encode(d) for d in data]).astype(np.float64)
+    scale = float(10 ** rng.uniform(-1.5, 2.9))
+    noise = float(rng.uniform(0.2, 1.4))
+    llr = ((2 * cws - 1) + rng.normal(0, noise, cws.shape)) * scale
+    u = rng.random(cws.shape)
+    p = rng.uniform(0, 0.02, 6) * (rng.random(6) < 0.5)
+    llr = np.where(u < p[0], np.inf, llr)
+    llr = np.where((u >= 0.1) & (u < 0.1 + p[1]), -np.inf, llr)
+    llr = np.where((u >= 0.2) & (u < 0.2 + p[2]), np.nan, llr)
+    llr = np.where((u >= 0.3) & (u < 0.3 + p[3]), 0.0, llr)
+    llr = np.where((u >= 0.4) & (u < 0.4 + p[4]), 1e-41 * np.sign(llr), llr)
+    llr = np.where((u >= 0.5) & (u < 0.5 + p[5]), rng.uniform(330, 360, cws.shape) * np.sign(llr), llr)
+    if rng.integers(0, 3) == 0:                                       # shortened codewords: a run of -15
+        cut = int(rng.integers(code.n - code.k, code.n))
+        llr[:, cut:] = -15.0
+    llr = llr.astype(np.float32)
+    max_it = int(rng.choice([1, 1, 2, 8, 15, 15, 15, 50]))
+    for arith, oa in (("gr_exact", oracle.GR_EXACT), ("fast", oracle.FAST)):
+        with np.errstate(all="ignore"):
+            ref_bits, ref_nit = code.decode_batch(llr, max_it=max_it, n_threads=8, arith=oa)
+        dec = dtl.ldpc_dec(alist, max_it=max_it, arith=arith)
+        bits, nit = dec.decode_batch(torch.from_numpy(llr).to(cuda))
+        np.testing.assert_array_equal(nit.cpu().numpy(), ref_nit, err_msg=arith)
+        np.testing.assert_array_equal(bits.cpu().numpy(), ref_bits, err_msg=arith)
