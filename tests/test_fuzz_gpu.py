@@ -176,3 +176,94 @@ def test_random_ldpc_inputs_match_oracle(oracle, dtl, cuda, seed):
         bits, nit = dec.decode_batch(torch.from_numpy(llr).to(cuda))
         np.testing.assert_array_equal(nit.cpu().numpy(), ref_nit, err_msg=arith)
         np.testing.assert_array_equal(bits.cpu().numpy(), ref_bits, err_msg=arith)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(80)))
+def test_random_demap_inputs_match_oracle(oracle, dtl, cuda, seed):
+    """The soft demapper alone on symbols no equaliser should produce (huge, tiny, denormal, infinite, NaN, exactly on a
+    constellation point or a decision boundary) and any noise power, every constellation, both distance modes, both
+    arithmetics: the same bits as the oracle (NaN in the same places)."""
+    import torch
+    from gr_dtl_amd import stages
+    rng = np.random.default_rng(52000 + seed)
+    cnst = int(rng.integers(1, 5))
+    n = int(rng.choice([1, 63, 64, 65, 1000, 4099]))
+    scale = float(10 ** rng.uniform(-3, 3))
+    z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * scale
+    u = rng.random(n)
+    special = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-41, -1e-41, 3e38, -3e38, 1.0, -1.0, 0.5, 2.0 / np.sqrt(10)])
+    re = np.where(u < 0.1, rng.choice(special, n), z.real)
+    im = np.where((u > 0.05) & (u < 0.15), rng.choice(special, n), z.imag)
+    syms = (re + 1j * im).astype(np.complex64)
+    noise = rng.choice([None, 0.0, 1e-42, 1e-30, 1e-6, 0.01, 0.3, 1.0, 50.0, 1e20, np.inf])
+    dist_mode = int(rng.integers(0, 2))
+    for arith, oa in (("gr_exact", oracle.GR_EXACT), ("fast", oracle.FAST)):
+        got = stages.soft_demap(torch.from_numpy(syms).to(cuda), cnst, noise, dist_mode, arith=arith).cpu().numpy()
+        want = oracle.soft_demap(cnst, syms, noise, dist_mode, arith=oa)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (cnst, dist_mode, noise, arith, int((~same).sum()), syms[np.nonzero(~same)[0][:4] // max(1, got.size // n)],
+                            got[~same][:4], want[~same][:4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_random_equalizer_inputs_match_oracle(oracle, dtl, cuda, seed):
+    """Channel estimator and payload frame equaliser alone on vectors that come from no transmitter: Gaussian carriers of
+    any scale with exact zeros and NaN mixed in, taps that are zero on some carriers (division by zero inside the
+    decision-directed recursion), every constellation and carrier offset.  Zeros compare without their sign."""
+    import torch
+    rng = np.random.default_rng(64000 + seed)
+    fft_len = int(rng.choice([64, 64, 128, 256]))
+    L = int(rng.integers(1, 13))
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=L)
+    rx = dtl.ofdm_receiver(pcfg)
+    n = int(rng.integers(1, 9))
+    # Not in the default set: denormals, |x| > 1e19 and infinities.  The equaliser's division sequences (no range scaling)
+    # and the offset search's NaN ordering are the reference's only for operands whose squares neither overflow nor
+    # underflow; outside that range both sides return garbage, but not the same garbage (DTL_FUZZ_SPECIALS explores it).
+    special = np.array([0.0, -0.0, np.nan], np.float64)
+    if os.environ.get("DTL_FUZZ_SPECIALS"):
+        special = np.array([float(v) for v in os.environ["DTL_FUZZ_SPECIALS"].split(",")])
+
+    def garbage(shape, p_special):
+        z = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 10 ** rng.uniform(-2, 2)
+        u = rng.random(shape)
+        re = np.where(u < p_special, rng.choice(special, shape), z.real)
+        im = np.where((u > p_special / 2) & (u < 1.5 * p_special), rng.choice(special, shape), z.imag)
+        return (re + 1j * im).astype(np.complex64)
+
+    p = float(rng.choice([0.0, 0.002, 0.05]))
+    if os.environ.get("DTL_FUZZ_NO_SPECIALS"):
+        p = 0.0
+    sync = garbage((n, 2, fft_len), p)
+    off, taps = rx.chanest(torch.from_numpy(sync).to(cuda))
+    off_h, taps_h = off.cpu().numpy(), taps.cpu().numpy()
+    with np.errstate(all="ignore"):
+        for j in range(n):
+            o_ref, t_ref = oracle.chanest(ocfg, sync[j])
+            assert off_h[j] == o_ref
+            same = (taps_h[j].view(np.float32) == t_ref.view(np.float32)) | (np.isnan(taps_h[j].view(np.float32)) & np.isnan(t_ref.view(np.float32)))
+            assert same.all(), ("taps", j, int((~same).sum()))
+    frames = garbage((n, L, fft_len), p)
+    taps_in = garbage((n, fft_len), float(rng.choice([0.0, 0.02])) if p else 0.0)
+    cn = [int(c) for c in rng.integers(1, 5, n)]
+    of = [int(o) for o in rng.choice([-4, -2, 0, 0, 0, 2, 4], n)]
+    ns = [int(s) for s in rng.integers(0, ocfg.frame_capacity + 1, n)]
+    hard, soft, syms, stats = rx.equalize_frames(torch.from_numpy(frames).to(cuda), torch.from_numpy(taps_in).to(cuda), cn, of, ns)
+    hard, soft, syms = hard.cpu().numpy(), soft.cpu().numpy(), syms.cpu().numpy()
+
+    def same_or_close(a, b, what):
+        a32, b32 = np.ascontiguousarray(a).view(np.float32), np.ascontiguousarray(b).view(np.float32)
+        ok = (a32 == b32) | (np.isnan(a32) & np.isnan(b32))
+        with np.errstate(all="ignore"):
+            ok |= np.abs(a32 - b32) <= 1e-5 * np.abs(b32) + 2e-6
+        assert ok.all(), (what, int((~ok).sum()), a32[~ok][:4], b32[~ok][:4])
+
+    with np.errstate(all="ignore"):
+        for j in range(n):
+            h_ref, s_ref, _, (snr_db, noise_db, noise_lin) = oracle.frame_equalize(ocfg, 0, cn[j], frames[j], of[j], taps_in[j])
+            same_or_close(hard[j], h_ref, "hard %d" % j)
+            same_or_close(soft[j], s_ref, "soft %d" % j)
+            for got, want in ((stats["snr_db"][j], snr_db), (stats["noise"][j], noise_lin)):
+                assert (got == want) or (np.isnan(got) and np.isnan(want)) or abs(got - want) <= 1e-5 * abs(want) + 1e-9, (j, got, want)
