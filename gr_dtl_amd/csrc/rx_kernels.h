@@ -28,6 +28,7 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
 int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
                     int stride, TbResult* res, int32_t* len, hipStream_t st, bool packed = false);
 int launch_expand_cw(const TbGather* tbs, int n_tbs, CwDesc* out, hipStream_t st);
+int launch_llr_gather(const LlrCopy* ops, int n_ops, float* llr, hipStream_t st);
 int launch_nofec_lengths(const int32_t* info, int n, int32_t* len, hipStream_t st);
 int launch_compact(const uint8_t* staging, int stride, const int32_t* len, int n, uint32_t* offs,
                    uint32_t* total, uint8_t* out, hipStream_t st);

@@ -1638,6 +1638,28 @@ int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int
     return DTL_OK;
 }
 
+// soft bits of irregular transport blocks -> contiguous scratch runs (one workgroup per piece)
+__global__ __launch_bounds__(256) void llr_gather_kernel(const LlrCopy* __restrict__ ops, int n_ops, float* __restrict__ llr)
+{
+    if (int(blockIdx.x) >= n_ops) return;
+    const LlrCopy op = ops[blockIdx.x];
+    float* dst = llr + op.dst;
+    if (op.src == 0xFFFFFFFFu) {
+        for (int i = threadIdx.x; i < op.len; i += 256) dst[i] = 0.0f;
+    } else {
+        const float* src = llr + op.src;
+        for (int i = threadIdx.x; i < op.len; i += 256) dst[i] = src[i];
+    }
+}
+
+int launch_llr_gather(const LlrCopy* ops, int n_ops, float* llr, hipStream_t st)
+{
+    if (n_ops <= 0) return DTL_OK;
+    hipLaunchKernelGGL(llr_gather_kernel, dim3(n_ops), dim3(256), 0, st, ops, n_ops, llr);
+    DTL_HIP_CHECK(hipGetLastError());
+    return DTL_OK;
+}
+
 int launch_expand_cw(const TbGather* tbs, int n_tbs, CwDesc* out, hipStream_t st)
 {
     if (n_tbs <= 0) return DTL_OK;

@@ -299,14 +299,14 @@ namespace {
 // descriptors are expanded on the device (expand_cw_kernel).
 struct TbAssembler {
     struct Seg { uint32_t off; int len; };
-    struct Done { TbGather g; int code, tb_no, tb_payload; };
+    struct Done { TbGather g; int code, tb_no, tb_payload; std::vector<Seg> pieces; }; // pieces: only of an irregular block
     std::vector<Seg> rcv;
     long rcv_size = 0, rcv_cap = 0, buf_idx = 0;
     int tb_number = -1;
     bool have_info = false;
     int info_tb_payload = 0, info_code = 0;
     std::vector<Done> done;
-    bool overflow = false; // a TB needed more than 4 source segments
+    bool irregular = false; // a block needs more pieces than a TbGather / CwDesc describes (Done::pieces holds them)
 
     void append(uint32_t base, long lo, long hi, long in_len)
     {
@@ -333,7 +333,13 @@ struct TbAssembler {
         d.code = info_code; d.tb_no = tb_no; d.tb_payload = tb_payload;
         TbGather& g = d.g;
         g.n_seg = int16_t(std::min<size_t>(rcv.size(), 4));
-        if (rcv.size() > 4) overflow = true;
+        // A gather recipe holds 4 pieces and a codeword's descriptor 2: enough when frames are used to their last bit
+        // (consecutive frames are one piece) and a loss or a constellation change splits a block now and then.  Frames
+        // whose bit capacity is not a whole number of bytes leave a gap after every frame: such a block keeps its piece
+        // list and is copied into one contiguous run first (stage_blocks) -- the reference's RCV_BUF, only for these.
+        bool many = rcv.size() > 4;
+        for (size_t i = 1; i + 1 < rcv.size(); i++) many = many || rcv[i].len < n; // a codeword could span 3 pieces
+        if (many) { d.pieces = rcv; irregular = true; }
         for (int i = 0; i < 4; i++) {
             g.seg_off[i] = i < g.n_seg ? rcv[i].off : 0xFFFFFFFFu;
             g.seg_len[i] = i < g.n_seg ? rcv[i].len : 0;
@@ -422,7 +428,7 @@ int tb_gather_frames(const std::vector<std::pair<int, int>>& code_nk, int capaci
         const int n_syms = fi.payload_len ? std::min(fi.n_payload_syms, capacity) : 0;
         DTL_TRY(tb_process_frame(asmb, fi, fi.cnst, n_syms, uint32_t(fi.llr_offset), capacity, dims));
     }
-    if (asmb.overflow) { set_last_error("transport block spread over more than 4 stream segments"); return DTL_ERR_UNSUPPORTED; }
+    if (asmb.irregular) { set_last_error("transport block spread over more pieces than a gather recipe holds (the whole-chain call copies such blocks; dtl_tb_gather does not own the soft-bit stream)"); return DTL_ERR_UNSUPPORTED; }
     gathers.clear(); spans.clear();
     uint32_t bits_base = 0, cw_first = 0;
     for (auto& d : asmb.done) {
@@ -1446,7 +1452,34 @@ int Receiver::stage_blocks(Call& c)
             DTL_TRY(tb_process_frame(asmb, fi, d.cnst, d.n_syms, base, capacity_, dims));
         }
     }
-    if (asmb.overflow) { set_last_error("transport block spread over more than 4 stream segments"); return DTL_ERR_UNSUPPORTED; }
+    // irregular blocks: their pieces go into contiguous runs behind the call's soft bits, the recipe then has one piece
+    std::vector<LlrCopy> llr_copies;
+    if (asmb.irregular) {
+        uint64_t at = uint64_t(n_llr);
+        for (auto& d : asmb.done) {
+            if (d.pieces.empty()) continue;
+            const uint64_t run = at;
+            for (const auto& sg : d.pieces) {
+                llr_copies.push_back({ sg.off, uint32_t(at), sg.len, 0 });
+                at += uint64_t(sg.len);
+            }
+            if (at + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
+            d.g.n_seg = 1;
+            d.g.seg_off[0] = uint32_t(run); d.g.seg_len[0] = int32_t(at - run);
+            for (int i = 1; i < 4; i++) { d.g.seg_off[i] = 0xFFFFFFFFu; d.g.seg_len[i] = 0; }
+            d.pieces.clear();
+        }
+        asmb.irregular = false;
+        const size_t need = (size_t(at) + 4096) * 4;
+        if (need > d_llr.cap) { // rare: grow the stream buffer, keeping what the payload kernels have written
+            DevBuf bigger;
+            DTL_TRY(bigger.ensure(need + need / 4));
+            if (d_llr.p && n_llr) DTL_HIP_CHECK(hipMemcpyAsync(bigger.p, d_llr.p, size_t(n_llr) * 4, hipMemcpyDeviceToDevice, st));
+            DTL_HIP_CHECK(hipStreamSynchronize(st));
+            std::swap(d_llr.p, bigger.p);
+            std::swap(d_llr.cap, bigger.cap);
+        }
+    }
     // global codeword order: grouped per LDPC code, TB order inside a group
     n_tbs = int(asmb.done.size());
     std::vector<TbGather> gathers(n_tbs);
@@ -1500,6 +1533,10 @@ int Receiver::stage_blocks(Call& c)
             DTL_TRY(d_staging_.ensure(size_t(n_tbs) * stride));
             DTL_TRY(upload_vec(h_gather_, d_tbgather_, gathers, st));
             DTL_TRY(upload_vec(h_tbdesc_, d_tbdesc_, tb_desc, st));
+            if (!llr_copies.empty()) {
+                DTL_TRY(upload_vec(h_llrcopy_, d_llrcopy_, llr_copies, st));
+                DTL_TRY(launch_llr_gather(d_llrcopy_.as<LlrCopy>(), int(llr_copies.size()), d_llr.as<float>(), st));
+            }
             DTL_TRY(launch_expand_cw(d_tbgather_.as<TbGather>(), n_tbs, d_cwdesc_.as<CwDesc>(), st));
             if (ev_[2]) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
             // the decoder packs its decisions (1 bit per bit) when every code in use runs on the node-parallel kernel:

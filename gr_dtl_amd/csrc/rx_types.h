@@ -125,6 +125,16 @@ struct TbGather {
     int32_t pad;
 };
 
+// One piece of a transport block whose soft bits are copied into a contiguous scratch run behind the call's soft-bit
+// stream (blocks spread over more pieces than a TbGather / CwDesc can describe): the reference's RCV_BUF copy, made
+// only for those blocks.
+struct LlrCopy {
+    uint32_t src;         // 0xFFFFFFFF = gap (never received): zeros
+    uint32_t dst;
+    int32_t len;
+    int32_t pad;
+};
+
 struct TbResult {
     int32_t crc_ok;
     int32_t avg_it;

@@ -341,7 +341,10 @@ typedef struct dtl_tb_span {
  * entries, FEC id i+1 -> entry i.  Writes one dtl_cw_desc per codeword to d_cw_desc (device, capacity cw_cap) for
  * dtl_ldpc_decode_gather (codewords of different codes are NOT regrouped: use spans[].fec) and one dtl_tb_span per
  * completed block to spans_host.  DTL_ERR_CAPACITY when a capacity is too small ("rcv buffer does not have enough
- * capacity!" likewise), DTL_ERR_TAGS_MISSING for a frame without a valid constellation.  Synchronises `stream`. */
+ * capacity!" likewise), DTL_ERR_TAGS_MISSING for a frame without a valid constellation, DTL_ERR_UNSUPPORTED for a block
+ * spread over more pieces of the stream than a descriptor pair holds (frames whose bit capacity is no whole number of
+ * bytes leave a gap behind every frame; dtl_rx_process copies such blocks into one run first, this entry point does not
+ * own the soft-bit stream and cannot).  Synchronises `stream`. */
 int dtl_tb_gather(const int32_t* code_n, const int32_t* code_k, int32_t n_codes, int32_t frame_capacity, int32_t max_bps,
                   const dtl_rx_frame_info* frames_host, int64_t n_frames, dtl_cw_desc* d_cw_desc, int64_t cw_cap,
                   int64_t* n_cw, dtl_tb_span* spans_host, int64_t span_cap, int64_t* n_spans, void* stream);

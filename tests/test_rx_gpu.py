@@ -236,3 +236,34 @@ def test_zz_soft_path_is_bit_reproducible():
         assert total > 10000, kind
         assert same / total > 0.999, (kind, same, total)
     print("bit-identical fraction:", {k: v[0] / max(v[1], 1) for k, v in STATS.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cnst,frame_length,fec,nbytes", [(1, 1, "n_0300_k_0152_gap_03.alist", 700), (1, 3, "n_0100_k_0027_gap_04.alist", 900),
+                                                         (3, 1, "n_0300_k_0152_gap_03.alist", 1500), (2, 2, "n_0100_k_0023_gap_10.alist", 400)])
+def test_frames_that_do_not_hold_whole_bytes(oracle, dtl, cuda, cnst, frame_length, fec, nbytes):
+    """50 data carriers (two of the four pilots given to data): a BPSK / 8PSK frame's bit capacity is no whole number of
+    bytes, so every frame leaves unused soft bits behind its payload and a transport block over many short frames is
+    many separate pieces of the soft-bit stream -- more than a gather recipe describes; such blocks are copied into one
+    run first (the reference's RCV_BUF).  Whole chain against the oracle, batch and streamed."""
+    import torch
+    from test_stream_gpu import _assert_same, _feed_all
+    pcfg, _, code = make_pair(oracle, dtl, frame_length=frame_length, fec=fec)
+    occ = tuple(sorted(tuple(pcfg.occupied_carriers[0]) + (-7, 7)))
+    pcfg.occupied_carriers = (occ,)
+    pcfg.pilot_carriers = ((-21, 21),)
+    pcfg.pilot_symbols = tuple(tuple(p[i] for i in (0, 3)) for p in pcfg.pilot_symbols)
+    ocfg = oracle.Config(fft_len=64, cp_len=pcfg.cp_len, frame_length=frame_length, has_fec=True, sync_threshold=pcfg.sync_threshold,
+                         use_sync_correct=pcfg.use_sync_correct, occupied_carriers=pcfg.occupied_carriers,
+                         pilot_carriers=pcfg.pilot_carriers, pilot_symbols=pcfg.pilot_symbols,
+                         sync_word1=pcfg.sync_word1, sync_word2=pcfg.sync_word2)
+    assert (ocfg.frame_capacity * cnst) % 8 != 0 or cnst == 2
+    user, hdrs, x = make_stream(oracle, ocfg, code, cnst, nbytes, 22.0 if cnst < 3 else 30.0, seed=4100 + cnst)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, max_frames=len(hdrs) + 64)
+    # (8PSK: a third of the blocks fail their CRC at any SNR -- the reference's symbol alignment of a block that starts
+    # inside a frame drops bits when the frame holds no whole number of bytes; reproduced, not repaired)
+    assert len(ref["tbs"]) >= 3 and sum(t["crc_ok"] for t in ref["tbs"]) >= (0.9 if cnst != 3 else 0.5) * len(ref["tbs"])
+    _compare(rx, res, ref, ocfg, True)
+    xt = torch.from_numpy(x).to(cuda)
+    cuts = list(range(777, x.size, 3 * ocfg.frame_samples + 11))
+    _assert_same(dtl.ofdm_receiver(pcfg).work(xt), _feed_all(dtl.ofdm_receiver(pcfg), xt, cuts))
