@@ -1719,7 +1719,7 @@ int launch_soft_demap(const cf32* syms, int64_t n, int cnst, double noise, int d
     constellation_points_host(cnst, pts.p);
     // soft_cf_impl.cc:89-103: sigma = sqrt(noise), or 0.001 when no estimate is available
     double sigma = 0.001;
-    if (noise >= 0) sigma = std::sqrt(noise);
+    if (!(noise < 0)) sigma = std::sqrt(noise); // negative: no estimate; a NaN estimate passes through like any tag value
     const float npwr = float(sigma), rinv = float(1.0 / double(npwr));
     const int64_t grid = (n + 255) / 256;
     const int mode = demap_mode(dist_mode);

@@ -1709,6 +1709,12 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     } reset_guard{ this, true };
     if (n < 0 || (!d_iq && n > 0)) { set_last_error("process: bad input"); return DTL_ERR_INVALID_ARG; }
     if (cfg.has_fec && decoders_.size() < 2) { set_last_error("Misconfiguration: decoder not found!"); return DTL_ERR_INVALID_ARG; }
+    {   // the header fields (32 bits, + 48 with FEC, + CRC-16) must fit the header symbols' data carriers: the reference's
+        // formatter would silently cut them off (packet_header.cc put_field guards) and nothing decodes
+        int bits = 0;
+        for (int i = 0; i < cfg.header_len(); i++) bits += int(cfg.occupied_carriers[size_t(i) % cfg.occupied_carriers.size()].size());
+        if (bits < (cfg.has_fec ? 96 : 48)) { set_last_error("header symbols hold fewer bits than the header fields"); return DTL_ERR_INVALID_ARG; }
+    }
     frames.clear(); tbs.clear(); raw_triggers.clear(); fixed_triggers.clear(); trigger_angles.clear();
     n_payload_frames = n_payload_bytes = n_llr = n_codewords = 0;
     for (double& s : stage_ms) s = 0.0;

@@ -148,7 +148,7 @@ void orc_soft_demap(int cnst, const orc_c32* syms, int n_syms, double noise, int
                     float* llr_out)
 {
     double sigma = 0.001;
-    if (noise >= 0) sigma = sqrt(noise);
+    if (!(noise < 0)) sigma = sqrt(noise); /* negative: no noise tag (soft_cf_impl.cc:89); a NaN estimate is a tag like any other */
     int bps = orc_bits_per_symbol(cnst);
     float msb[4];
     for (int i = 0; i < n_syms; i++) {

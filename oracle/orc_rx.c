@@ -40,6 +40,7 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
     const int h = cfg->header_len, L = cfg->frame_length, hdr_syms = 2 + h;
     const int cap = orc_frame_capacity(cfg);
     const int hdr_bits_len = h * cfg->occ_len[0];
+    if (hdr_bits_len < (cfg->has_fec ? 96 : 48)) return -3; /* the header fields do not fit: nothing would decode */
 
     uint8_t* trig_raw = (uint8_t*)malloc(n);
     uint8_t* trig_fix = (uint8_t*)malloc(n);

@@ -10,12 +10,15 @@ ES = {1: 1.0, 2: 0.25, 3: 1.0, 4: 1.0}  # mean symbol energy of each constellati
 
 
 def make_pair(oracle, dtl, fft_len=64, frame_length=20, fec="n_0300_k_0152_gap_03.alist", sync_threshold=0.95,
-              use_sync_correct=True, llr_dist_mode=0, arith="gr_exact"):
-    """-> (product ofdm_adaptive_rx_config, oracle Config, oracle Ldpc or None)"""
+              use_sync_correct=True, llr_dist_mode=0, arith="gr_exact", carriers=None):
+    """-> (product ofdm_adaptive_rx_config, oracle Config, oracle Ldpc or None)
+    carriers: (occupied sets, pilot sets, pilot symbol rows) replacing the default carrier plan."""
     if fft_len == 64:
         pcfg = dtl.ofdm_adaptive_rx_config(frame_length=frame_length)
     else:
         pcfg = dtl.make_scaled_rx_config(fft_len, frame_length=frame_length)
+    if carriers is not None:
+        pcfg.occupied_carriers, pcfg.pilot_carriers, pcfg.pilot_symbols = carriers
     pcfg.sync_threshold = sync_threshold
     pcfg.use_sync_correct = use_sync_correct
     pcfg.llr_dist_mode = llr_dist_mode

@@ -14,14 +14,27 @@ from test_stream_gpu import _assert_same, _feed_all
 CODES = ("n_0300_k_0152_gap_03.alist", "n_0100_k_0023_gap_10.alist", "n_0100_k_0027_gap_04.alist")
 
 
-def _scenario(oracle, dtl, rng):
+def _scenario(oracle, dtl, rng, plans=False):
     fft_len = int(rng.choice([64, 64, 128, 256]))
     frame_length = int(rng.integers(1, 21)) if fft_len == 64 else int(rng.integers(2, 13))
     fec = rng.choice([None, *CODES]) if fft_len == 64 else rng.choice(CODES)
     thr = float(rng.choice([0.95, 0.95, 0.9, 0.97]))
+    carriers = None
+    if plans and fft_len == 64 and rng.integers(0, 3) == 0:
+        # a carrier plan of its own: the 52 carriers the sync words cover, 2 .. 4 of them pilots anywhere (48 .. 50 data
+        # carriers: the header needs 48 per symbol), one or two pilot sets (the second with fewer pilots: ragged
+        # tables), fresh pilot symbols
+        used = [c for c in range(-26, 27) if c]
+        pil = sorted(int(c) for c in rng.choice(used, int(rng.choice([2, 3, 4])), replace=False))
+        occ = tuple(c for c in used if c not in pil)
+        sets = (tuple(pil),) if rng.integers(0, 2) else (tuple(pil), tuple(pil[:len(pil) // 2]))
+        rows = tuple(tuple(complex(v) for v in rng.choice([-1.0, 1.0], len(sets[i % len(sets)])))
+                     for i in range(len(sets) * int(rng.choice([1, 2, 3]))))     # row i belongs to pilot set i mod n_sets
+        carriers = ((occ,), sets, rows)
     pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, fec=None if fec is None else str(fec),
                                  sync_threshold=thr, use_sync_correct=bool(rng.integers(0, 2)),
-                                 llr_dist_mode=int(rng.integers(0, 2)), arith=str(rng.choice(["gr_exact", "gr_exact", "fast"])))
+                                 llr_dist_mode=int(rng.integers(0, 2)), arith=str(rng.choice(["gr_exact", "gr_exact", "fast"])),
+                                 carriers=carriers)
     n_seg = int(rng.integers(1, 4))
     impair = bool(rng.integers(0, 2))
     channel = None
@@ -101,6 +114,17 @@ def test_random_scenario_matches_oracle(oracle, dtl, cuda, seed):
         np.testing.assert_array_equal(streamed[3], batch.raw_triggers)
         return
     _assert_same(batch, streamed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("DTL_FUZZ_PLAN_FIRST", "0")), int(os.environ.get("DTL_FUZZ_PLAN_LAST", "240")))))
+def test_random_scenario_with_carrier_plans(oracle, dtl, cuda, seed):
+    """As above, a third of the 64-carrier scenarios on a random carrier plan (48 .. 50 data carriers, pilots anywhere,
+    ragged pilot sets: frame capacities that hold no whole number of bytes)."""
+    rng = np.random.default_rng(123000 + seed)
+    pcfg, ocfg, code, x, info = _scenario(oracle, dtl, rng, plans=True)
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, max_frames=x.size // 64 + 16)
+    _compare(rx, res, ref, ocfg, code is not None)
 
 
 @pytest.mark.gpu

@@ -52,3 +52,18 @@ def test_pathological_streams(oracle, dtl, cuda, sync_correct):
         # ... and the receiver still decodes a good stream afterwards
         again = rx.work(torch.from_numpy(good).to(cuda)).payload.cpu().numpy()
         np.testing.assert_array_equal(again, want, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_header_that_does_not_fit_is_refused(oracle, dtl, cuda):
+    """40 data carriers: the 96 header bits (FEC) do not fit two header symbols -- the reference's formatter would cut the
+    fields off and nothing would ever decode; the receiver says so instead."""
+    import torch
+    pcfg = dtl.ofdm_adaptive_rx_config(frame_length=4)
+    pcfg.occupied_carriers = (tuple(pcfg.occupied_carriers[0])[4:-4],)
+    pcfg.fec_codes = (("fec_1", "n_0300_k_0152_gap_03.alist"),)
+    pcfg.mcs = ((-100000, (dtl.constellation_type_t.BPSK, "fec_1")),)
+    rx = dtl.ofdm_receiver(pcfg)
+    with pytest.raises(dtl._lib.DtlError) as e:
+        rx.work(torch.zeros(5000, dtype=torch.complex64, device=cuda))
+    assert e.value.code == dtl._lib.ERR_INVALID_ARG and "header" in str(e.value)
