@@ -11,6 +11,7 @@ from helpers import ES, make_pair
 from test_rx_gpu import _compare, _run_both
 from test_stream_gpu import _assert_same, _feed_all
 
+AUX = int(os.environ.get("DTL_FUZZ_AUX", "1"))     # multiplies the seed counts of the block-level tests below
 CODES = ("n_0300_k_0152_gap_03.alist", "n_0100_k_0023_gap_10.alist", "n_0100_k_0027_gap_04.alist")
 
 
@@ -128,7 +129,7 @@ def test_random_scenario_with_carrier_plans(oracle, dtl, cuda, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(150)))
+@pytest.mark.parametrize("seed", list(range(150 * AUX)))
 def test_random_tx_matches_oracle(oracle, dtl, cuda, seed):
     """The batched transmitter against the oracle's: framing, header fields and on-air samples bit for bit."""
     import torch
@@ -164,7 +165,7 @@ def test_random_tx_matches_oracle(oracle, dtl, cuda, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(120)))
+@pytest.mark.parametrize("seed", list(range(120 * AUX)))
 def test_random_ldpc_inputs_match_oracle(oracle, dtl, cuda, seed):
     """The belief-propagation decoder alone on soft bits no demapper would produce: random scale, sign errors, runs of
     shortened positions, +-inf, NaN, zeros, denormals, exponents near the "tame" bound of the shortened division
@@ -203,7 +204,7 @@ def test_random_ldpc_inputs_match_oracle(oracle, dtl, cuda, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(80)))
+@pytest.mark.parametrize("seed", list(range(80 * AUX)))
 def test_random_demap_inputs_match_oracle(oracle, dtl, cuda, seed):
     """The soft demapper alone on symbols no equaliser should produce (huge, tiny, denormal, infinite, NaN, exactly on a
     constellation point or a decision boundary) and any noise power, every constellation, both distance modes, both
@@ -231,7 +232,7 @@ def test_random_demap_inputs_match_oracle(oracle, dtl, cuda, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(60)))
+@pytest.mark.parametrize("seed", list(range(60 * AUX)))
 def test_random_equalizer_inputs_match_oracle(oracle, dtl, cuda, seed):
     """Channel estimator and payload frame equaliser alone on vectors that come from no transmitter: Gaussian carriers of
     any scale with exact zeros and NaN mixed in, taps that are zero on some carriers (division by zero inside the
