@@ -2,7 +2,8 @@
 """Loop an adaptive-OFDM link on one MI355X: GPU transmitter -> AWGN -> GPU receiver, fed to the receiver in
 arbitrary slices the way a GNU Radio scheduler would, with the reference's telemetry shapes on the way out.
 
-    python examples/loopback.py --snr 24 --constellation 4 --bytes 200000
+    python examples/loopback.py [--snr 24 --constellation 4 --bytes 200000]   (the defaults: a link that works;
+    --snr 12 shows what the monitor reports when synchronisation starts to fail)
 """
 import argparse
 import os
@@ -16,9 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fft", type=int, default=64)
-    ap.add_argument("--constellation", type=int, default=2, help="1 BPSK, 2 QPSK, 3 8PSK, 4 16QAM")
-    ap.add_argument("--snr", type=float, default=16.0, help="Es/N0 of a unit-energy carrier, dB")
-    ap.add_argument("--bytes", type=int, default=100000)
+    ap.add_argument("--constellation", type=int, default=4, help="1 BPSK, 2 QPSK, 3 8PSK, 4 16QAM")
+    ap.add_argument("--snr", type=float, default=24.0, help="Es/N0 of a unit-energy carrier, dB")
+    ap.add_argument("--bytes", type=int, default=200000)
     ap.add_argument("--slice", type=int, default=50000, help="samples per feed() call")
     args = ap.parse_args()
     import torch
