@@ -451,9 +451,10 @@ int dtl_tb_gather(const int32_t* code_n, const int32_t* code_k, int32_t n_codes,
     *n_spans = int64_t(spans.size());
     if (int64_t(spans.size()) > span_cap || total_cw > cw_cap) { dtl::set_last_error("tb_gather: output capacity too small"); return DTL_ERR_CAPACITY; }
     if (spans.empty()) return DTL_OK;
-    if (!d_cw_desc || !spans_host) { dtl::set_last_error("tb_gather: null output"); return DTL_ERR_INVALID_ARG; }
-    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
+    if (!spans_host) { dtl::set_last_error("tb_gather: null output"); return DTL_ERR_INVALID_ARG; }
     std::memcpy(spans_host, spans.data(), spans.size() * sizeof(dtl::TbSpan));
+    if (!d_cw_desc) return DTL_OK; // block bookkeeping only (host work: no device needed)
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     dtl::DevBuf d_g;
     rc = d_g.ensure(gathers.size() * sizeof(dtl::TbGather));

@@ -340,7 +340,7 @@ typedef struct dtl_tb_span {
  * bit in the soft-bit stream; frames with header_ok == 0 or llr_offset < 0 are skipped).  code_n / code_k: n_codes
  * entries, FEC id i+1 -> entry i.  Writes one dtl_cw_desc per codeword to d_cw_desc (device, capacity cw_cap) for
  * dtl_ldpc_decode_gather (codewords of different codes are NOT regrouped: use spans[].fec) and one dtl_tb_span per
- * completed block to spans_host.  DTL_ERR_CAPACITY when a capacity is too small ("rcv buffer does not have enough
+ * completed block to spans_host (d_cw_desc == NULL: the block records only, no device work).  DTL_ERR_CAPACITY when a capacity is too small ("rcv buffer does not have enough
  * capacity!" likewise), DTL_ERR_TAGS_MISSING for a frame without a valid constellation, DTL_ERR_UNSUPPORTED for a block
  * spread over more pieces of the stream than a descriptor pair holds (frames whose bit capacity is no whole number of
  * bytes leave a gap behind every frame; dtl_rx_process copies such blocks into one run first, this entry point does not

@@ -224,3 +224,61 @@ def test_product_constellation_tables_against_reference_constants(oracle, dtl):
     assert abs(abs(p8[0] - pb[0]) ** 2 / dmin2 - G["constellation_metric"]["value"]) < 1e-5
     assert abs(p8[0] - np.exp(1j * np.pi / 8)) < 1e-6 and pb[0] == -1
     assert L.dtl_constellation_points_host(9, buf.ctypes.data, C.byref(n)) == dtl._lib.ERR_INVALID_ARG
+
+
+def test_transport_block_bookkeeping_matches_oracle(oracle, dtl):
+    """dtl_tb_gather without a descriptor table (host work only): which transport blocks a run of frame headers completes
+    -- block numbers, payload sizes, codeword counts -- against the oracle's tb_decoder restatement fed with the same
+    headers, over constellation changes, lost frames and frames cut out of the middle of a block."""
+    from gr_dtl_amd.ofdm_receiver import _FRAME_DTYPE, TbSpan
+    L = dtl._lib.lib()
+    rng = np.random.default_rng(77)
+    cap = 96
+    compared = blocks = 0
+    for case in range(40):
+        alist = [ALIST_300, ALIST_100_23, ALIST_100_27][case % 3]
+        code = oracle.Ldpc(alist)
+        hdrs, cnsts = [], []
+        frame_no = int(rng.integers(0, 4000))
+        for seg in range(int(rng.integers(1, 4))):
+            cnst = int(rng.integers(1, 5))
+            if (max(1, 1 + (cap * cnst // 8 * 8) // code.n) * code.k) // 8 <= 4:
+                cnst = 4
+            user = rng.integers(0, 256, int(rng.integers(1, 40 * cap * cnst // 8)), dtype=np.uint8)
+            _, hh = oracle.fec_frames_build(code, 1, cnst, cap, user, first_frame_no=frame_no)
+            frame_no = (frame_no + len(hh)) & 0xFFF
+            hdrs += hh
+        keep = rng.random(len(hdrs)) > (0.0 if case % 4 == 0 else 0.12)           # lost frames
+        hdrs = [h for h, k in zip(hdrs, keep) if k]
+        if not hdrs:
+            continue
+        # product: frame records with consecutive soft-bit offsets
+        fr = np.zeros(len(hdrs), dtype=_FRAME_DTYPE)
+        off = 0
+        tbd = oracle.TbDecoder(code, cap)
+        want = []
+        for i, h in enumerate(hdrs):
+            bps = min(h["cnst"], 4)
+            n_syms = min(-(-8 * h["payload_len"] // bps), cap)
+            fr[i]["header_ok"] = 1
+            for k in ("payload_len", "frame_no", "cnst", "fb_cnst", "tb_no", "fec_fb", "tb_offset", "fec", "tb_payload"):
+                fr[i][k] = h[k]
+            fr[i]["n_payload_syms"], fr[i]["payload_index"], fr[i]["llr_offset"] = n_syms, i, off
+            off += n_syms * bps
+            _, recs = tbd.frame(np.full(n_syms * bps, -5.0, np.float32), h["cnst"], h)   # soft bits of an all-zero word
+            want += [(r["tb_no"], r["tb_payload"]) for r in recs]
+        cn, ck = np.array([code.n], np.int32), np.array([code.k], np.int32)
+        spans = (TbSpan * (2 * len(hdrs) + 4))()
+        n_cw, n_sp = C.c_int64(0), C.c_int64(0)
+        rc = L.dtl_tb_gather(cn.ctypes.data_as(C.c_void_p), ck.ctypes.data_as(C.c_void_p), 1, cap, 4, fr.ctypes.data_as(C.c_void_p),
+                             C.c_int64(len(hdrs)), None, C.c_int64(1 << 40), C.byref(n_cw), spans, C.c_int64(len(spans)),
+                             C.byref(n_sp), None)
+        if rc == dtl._lib.ERR_UNSUPPORTED:     # a block of many pieces (frames lost inside it): the whole-chain call's job
+            continue
+        assert rc == 0, dtl._lib.last_error()
+        got = [(spans[i].tb_no, spans[i].tb_payload_bits) for i in range(n_sp.value)]
+        assert got == want, case
+        assert n_cw.value == sum(spans[i].n_cw for i in range(n_sp.value))
+        compared += 1
+        blocks += len(got)
+    assert compared >= 30 and blocks >= 300, (compared, blocks)
