@@ -16,8 +16,8 @@ CODES = ("n_0300_k_0152_gap_03.alist", "n_0100_k_0023_gap_10.alist", "n_0100_k_0
 
 
 def _scenario(oracle, dtl, rng, plans=False):
-    fft_len = int(rng.choice([64, 64, 128, 256]))
-    frame_length = int(rng.integers(1, 21)) if fft_len == 64 else int(rng.integers(2, 13))
+    fft_len = int(rng.choice([64, 64, 64, 128, 128, 256, 256, 512, 1024] if plans else [64, 64, 128, 256]))
+    frame_length = int(rng.integers(1, 21)) if fft_len == 64 else int(rng.integers(2, 13)) if fft_len <= 256 else int(rng.integers(2, 6))
     fec = rng.choice([None, *CODES]) if fft_len == 64 else rng.choice(CODES)
     thr = float(rng.choice([0.95, 0.95, 0.9, 0.97]))
     carriers = None
@@ -44,7 +44,7 @@ def _scenario(oracle, dtl, rng, plans=False):
         channel = (rng.normal(0, 1, taps) + 1j * rng.normal(0, 1, taps)) * np.exp(-0.7 * np.arange(taps))
         channel[0] = 1.0
         channel = (channel / np.sqrt(np.sum(np.abs(channel) ** 2))).astype(np.complex64)
-    parts, frame_no, tb_no = [], 0, 0
+    parts, frame_no, tb_no = [], (int(rng.integers(0, 4096)) if plans else 0), 0   # (plans: the 12-bit frame counter wraps)
     worst = 0.0
     gap = int(rng.choice([0, 0, 0, 7, 64]))
     for _ in range(n_seg):
@@ -120,8 +120,9 @@ def test_random_scenario_matches_oracle(oracle, dtl, cuda, seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("DTL_FUZZ_PLAN_FIRST", "0")), int(os.environ.get("DTL_FUZZ_PLAN_LAST", "240")))))
 def test_random_scenario_with_carrier_plans(oracle, dtl, cuda, seed):
-    """As above, a third of the 64-carrier scenarios on a random carrier plan (48 .. 50 data carriers, pilots anywhere,
-    ragged pilot sets: frame capacities that hold no whole number of bytes)."""
+    """As above, with 512- and 1024-point FFTs, a frame counter that starts anywhere (and wraps), and a third of the
+    64-carrier scenarios on a random carrier plan (48 .. 50 data carriers, pilots anywhere, ragged pilot sets: frame
+    capacities that hold no whole number of bytes)."""
     rng = np.random.default_rng(123000 + seed)
     pcfg, ocfg, code, x, info = _scenario(oracle, dtl, rng, plans=True)
     rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, max_frames=x.size // 64 + 16)
