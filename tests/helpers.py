@@ -10,7 +10,7 @@ ES = {1: 1.0, 2: 0.25, 3: 1.0, 4: 1.0}  # mean symbol energy of each constellati
 
 
 def make_pair(oracle, dtl, fft_len=64, frame_length=20, fec="n_0300_k_0152_gap_03.alist", sync_threshold=0.95,
-              use_sync_correct=True, llr_dist_mode=0, arith="gr_exact", carriers=None):
+              use_sync_correct=True, llr_dist_mode=0, arith="gr_exact", carriers=None, scramble=False, max_it=15, bp_sigma=0.0):
     """-> (product ofdm_adaptive_rx_config, oracle Config, oracle Ldpc or None)
     carriers: (occupied sets, pilot sets, pilot symbol rows) replacing the default carrier plan."""
     if fft_len == 64:
@@ -19,6 +19,9 @@ def make_pair(oracle, dtl, fft_len=64, frame_length=20, fec="n_0300_k_0152_gap_0
         pcfg = dtl.make_scaled_rx_config(fft_len, frame_length=frame_length)
     if carriers is not None:
         pcfg.occupied_carriers, pcfg.pilot_carriers, pcfg.pilot_symbols = carriers
+    pcfg.scramble_bits = bool(scramble)
+    pcfg.ldpc_max_iterations = int(max_it)
+    pcfg.ldpc_sigma = float(bp_sigma)
     pcfg.sync_threshold = sync_threshold
     pcfg.use_sync_correct = use_sync_correct
     pcfg.llr_dist_mode = llr_dist_mode
@@ -32,7 +35,8 @@ def make_pair(oracle, dtl, fft_len=64, frame_length=20, fec="n_0300_k_0152_gap_0
                          sync_threshold=sync_threshold, use_sync_correct=use_sync_correct,
                          occupied_carriers=pcfg.occupied_carriers, pilot_carriers=pcfg.pilot_carriers,
                          pilot_symbols=pcfg.pilot_symbols, sync_word1=pcfg.sync_word1, sync_word2=pcfg.sync_word2,
-                         llr_dist_mode=llr_dist_mode, arith={"gr_exact": 0, "fast": 1}[arith])
+                         llr_dist_mode=llr_dist_mode, arith={"gr_exact": 0, "fast": 1}[arith], scramble_header=bool(scramble),
+                         max_it=int(max_it), bp_sigma=float(np.float32(bp_sigma)) if bp_sigma else float(np.sqrt(np.float32(2.0))))
     code = oracle.Ldpc(os.path.join(CODES, fec)) if fec else None
     return pcfg, ocfg, code
 

@@ -20,6 +20,11 @@ def _scenario(oracle, dtl, rng, plans=False):
     frame_length = int(rng.integers(1, 21)) if fft_len == 64 else int(rng.integers(2, 13)) if fft_len <= 256 else int(rng.integers(2, 6))
     fec = rng.choice([None, *CODES]) if fft_len == 64 else rng.choice(CODES)
     thr = float(rng.choice([0.95, 0.95, 0.9, 0.97]))
+    knobs = {}
+    if plans:   # the decoder's iteration limit and its channel sigma (never set by the reference's flowgraphs); not header
+        # scrambling: the reference's parser does not undo the formatter's mask (packet_header.cc:194-197 vs :231-312) --
+        # with it no header passes its CRC, in the reference, the oracle and the product alike
+        knobs = dict(max_it=int(rng.choice([15, 15, 5, 30])), bp_sigma=float(rng.choice([0.0, 0.0, 1.0, 2.5])))
     carriers = None
     if plans and fft_len == 64 and rng.integers(0, 3) == 0:
         # a carrier plan of its own: the 52 carriers the sync words cover, 2 .. 4 of them pilots anywhere (48 .. 50 data
@@ -35,7 +40,7 @@ def _scenario(oracle, dtl, rng, plans=False):
     pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, fec=None if fec is None else str(fec),
                                  sync_threshold=thr, use_sync_correct=bool(rng.integers(0, 2)),
                                  llr_dist_mode=int(rng.integers(0, 2)), arith=str(rng.choice(["gr_exact", "gr_exact", "fast"])),
-                                 carriers=carriers)
+                                 carriers=carriers, **knobs)
     n_seg = int(rng.integers(1, 4))
     impair = bool(rng.integers(0, 2))
     channel = None
