@@ -244,6 +244,7 @@ void orc_fix_sync(orc_framedetect* s, const uint8_t* in, uint8_t* out, int len);
 
 /* delay(N+cp) + frequency_modulator_fc(-2/N) + multiply_cc (ofdm_receiver.py:73-76,88-89) */
 void orc_cfo_mix(const orc_cfg* cfg, const orc_c32* iq, long n, const float* angle, orc_c32* out);
+void orc_cfo_mix_trig(const orc_cfg* cfg, const orc_c32* iq, long n, const float* angle, const uint8_t* trig, orc_c32* out);
 
 /* GR3.10 ofdm_chanest_vcvc(sync1, sync2, h) (ofdm_receiver.py:102-103): in = 2 x N (FFT'd sync
  * symbols); out: integer carrier offset + N taps */

@@ -524,11 +524,14 @@ def fix_sync(frame_len, trig, chunk=None):
     return out, st
 
 
-def cfo_mix(cfg, iq, angle):
+def cfo_mix(cfg, iq, angle, trig=None):
+    """trig: the raw trigger flags (uint8 per sample): an oscillator segment starts at every trigger; without them, where
+    the held angle changes."""
     iq = np.ascontiguousarray(iq, dtype=c32)
     angle = np.ascontiguousarray(angle, dtype=np.float32)
     out = np.zeros_like(iq)
-    lib().orc_cfo_mix(C.byref(cfg.c), _ptr(iq), C.c_long(iq.size), _ptr(angle), _ptr(out))
+    t = None if trig is None else np.ascontiguousarray(trig, dtype=np.uint8)
+    lib().orc_cfo_mix_trig(C.byref(cfg.c), _ptr(iq), C.c_long(iq.size), _ptr(angle), None if t is None else _ptr(t), _ptr(out))
     return out
 
 

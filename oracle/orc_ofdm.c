@@ -280,19 +280,45 @@ void orc_fix_sync(orc_framedetect* s, const uint8_t* in, uint8_t* out, int len)
     if (!trigger_found) s->remainder += len;
 }
 
-/* delay(N+cp) ; frequency_modulator_fc(-2.0/N) ; multiply_cc.  The oscillator phase is kept in
- * double and wrapped to [-pi, pi) (the reference keeps a float accumulator and a fixed-point
- * sin/cos table: ~1e-4 of its own error). */
-void orc_cfo_mix(const orc_cfg* cfg, const orc_c32* iq, long n, const float* angle, orc_c32* out)
+/* delay(N+cp) ; frequency_modulator_fc(-2.0/N) ; multiply_cc.  The oscillator phase is kept in double and wrapped
+ * to [-pi, pi) (the reference keeps a float accumulator and a fixed-point sin/cos table: ~1e-4 of its own error).
+ * The held angle is constant between triggers, so the integral is written in closed form per segment instead of
+ * as n sequential additions:
+ *     phase(i) = wrap(phase0 + (double)(sens * angle) * (i - start + 1)),   i in [start, next start)
+ *     phase0 of the next segment = wrap(phase0 + (double)(sens * angle) * (next start - start))
+ * -- one rounding per sample instead of an accumulated one, and the form a parallel implementation can evaluate
+ * for any sample on its own (the HIP kernel does: identical bits).  trig (may be NULL): the raw trigger flags; a
+ * segment starts at every trigger, also when the new angle equals the old one.  Without it a segment starts where
+ * the held angle changes. */
+static double wrap_segment_phase(double phase)
+{
+    const double two_pi = 2.0 * M_PI, x = phase + M_PI;
+    if (x >= 0.0 && x < two_pi) phase = x;
+    else if (x >= two_pi && x < 2.0 * two_pi) phase = x - two_pi;
+    else phase = fmod(x, two_pi);
+    if (phase < 0) phase += 2.0 * M_PI;
+    return phase - M_PI;
+}
+
+void orc_cfo_mix_trig(const orc_cfg* cfg, const orc_c32* iq, long n, const float* angle, const uint8_t* trig, orc_c32* out)
 {
     const int dly = cfg->fft_len + cfg->cp_len;
     const float sens = (float)(-2.0 / cfg->fft_len);
-    double phase = 0;
+    double phase0 = 0;
+    long start = -1;       /* no segment yet: the held angle is 0 and the phase stays 0 */
+    float seg_angle = 0;
     for (long i = 0; i < n; i++) {
-        phase = phase + (double)(sens * angle[i]);
-        phase = fmod(phase + M_PI, 2.0 * M_PI);
-        if (phase < 0) phase += 2.0 * M_PI;
-        phase -= M_PI;
+        const int new_seg = trig ? trig[i] : (i == 0 ? angle[0] != 0.0f : angle[i] != angle[i - 1]);
+        if (new_seg) {
+            phase0 = (start >= 0) ? wrap_segment_phase(phase0 + (double)(sens * seg_angle) * (double)(i - start)) : 0.0;
+            start = i;
+            seg_angle = angle[i];
+        }
+        double phase = 0;
+        if (start >= 0) {
+            phase = phase0 + (double)(sens * seg_angle) * (double)(i - start + 1);
+            phase -= (2.0 * M_PI) * floor((phase + M_PI) * (1.0 / (2.0 * M_PI)));
+        }
         float ph = (float)phase, sn, cs;
         orc_sincosf(ph, &sn, &cs); /* sincosf with a fixed operation sequence, orc_math.h */
         cf osc = cs + sn * I;
@@ -301,6 +327,11 @@ void orc_cfo_mix(const orc_cfg* cfg, const orc_c32* iq, long n, const float* ang
                (crealf(smp) * cimagf(osc) + cimagf(smp) * crealf(osc)) * I;
         out[i] = from_cf(r);
     }
+}
+
+void orc_cfo_mix(const orc_cfg* cfg, const orc_c32* iq, long n, const float* angle, orc_c32* out)
+{
+    orc_cfo_mix_trig(cfg, iq, n, angle, NULL, out);
 }
 
 /* ------------------------------------------------------------------ channel estimate */

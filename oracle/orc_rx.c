@@ -54,7 +54,7 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
     } else {
         memcpy(trig_fix, trig_raw, n);
     }
-    orc_cfo_mix(cfg, iq, n, angle, mixed);
+    orc_cfo_mix_trig(cfg, iq, n, angle, trig_raw, mixed);
     if (o->trig_raw) memcpy(o->trig_raw, trig_raw, n);
     if (o->trig_fixed) memcpy(o->trig_fixed, trig_fix, n);
     if (o->angle) memcpy(o->angle, angle, n * sizeof(float));
