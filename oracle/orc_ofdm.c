@@ -153,7 +153,6 @@ void orc_sync_sc(const orc_cfg* cfg, const orc_c32* iq, long n, float* metric_ou
     const int N = cfg->fft_len, half = N / 2, max_len = cfg->cp_len;
     const float thr = cfg->sync_threshold;
     float* metric = metric_out ? metric_out : (float*)malloc(n * sizeof(float));
-    float* arg = (float*)malloc(n * sizeof(float));
     /* delay(N/2) -> conjugate -> multiply_cc -> fir_filter_ccf(N/2 taps of -1)   [P]
      * complex_to_mag_squared -> fir_filter_fff(N taps of 0.5) -> multiply_ff(x,x) [E^2]
      * metric = |P|^2 / E^2 ; angle = arg(P).  Window sums are accumulated in double and
@@ -190,9 +189,6 @@ void orc_sync_sc(const orc_cfg* cfg, const orc_c32* iq, long n, float* metric_ou
         float Pr = (float)(-pr), Pi = (float)(-pi), E = (float)en;
         float num = Pr * Pr + Pi * Pi;
         metric[i] = num / (E * E);
-        /* complex_to_arg: the reference uses a table/polynomial atan2 approximation (1e-4 rad);
-         * restated as the correctly rounded value: atan2 in double, rounded to float once */
-        arg[i] = (float)atan2((double)Pi, (double)Pr);
     }
     /* plateau_detector_fb(max_len = cp_len, threshold), unbounded-buffer form */
     memset(trig, 0, n);
@@ -206,14 +202,31 @@ void orc_sync_sc(const orc_cfg* cfg, const orc_c32* iq, long n, float* metric_ou
             }
         }
     }
-    /* sample_and_hold_ff */
+    /* sample_and_hold_ff of complex_to_arg (the reference: a table / polynomial atan2 approximation, 1e-4 rad; restated
+     * as atan2 in double, rounded to float once).  The value that is held is re-formed from a FRESH sum over the trigger's
+     * window (the reference's FIR starts every output from zero): the running sums above carry the rounding residue of
+     * the whole stream before them, ~1e-17 of a component that is exactly 0 for a noise-free preamble -- which turned a
+     * held angle of exactly 0 into 5e-17 and the derotated samples' zero components into denormal-sized ones.  64
+     * interleaved partial sums combined as a binary tree: the order a 64-lane reduction adds them in. */
     float held = 0;
     for (long i = 0; i < n; i++) {
-        if (trig[i]) held = arg[i];
+        if (trig[i]) {
+            double sr[64], si[64];
+            for (int l = 0; l < 64; l++) sr[l] = si[l] = 0.0;
+            for (int m = 0; m < half; m++) {
+                const long a_i = i - m, b_i = i - m - half;
+                const orc_c32 z = { 0, 0 };
+                const orc_c32 a = (a_i >= 0 && a_i < n) ? iq[a_i] : z, b = (b_i >= 0 && b_i < n) ? iq[b_i] : z;
+                sr[m & 63] += (double)(a.re * b.re + a.im * b.im);
+                si[m & 63] += (double)(a.im * b.re - a.re * b.im);
+            }
+            for (int off = 32; off > 0; off >>= 1)
+                for (int l = 0; l < off; l++) { sr[l] += sr[l + off]; si[l] += si[l + off]; }
+            held = (float)atan2((double)(float)(-si[0]), (double)(float)(-sr[0]));
+        }
         angle[i] = held;
     }
     if (!metric_out) free(metric);
-    free(arg);
 }
 
 void orc_framedetect_init(orc_framedetect* s, int frame_len)
