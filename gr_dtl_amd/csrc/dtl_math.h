@@ -70,6 +70,38 @@ __device__ __forceinline__ double dm_exp64(double x)
     return (x != x) ? x : res;
 }
 
+// log / log10 / 10^y in double, written out (oracle/orc_math.h orc_log, orc_log10, orc_pow10 execute the same sequence):
+// the frame's SNR and noise figures scale every soft bit of the frame, and ocml's log10 / pow differ from the C library's
+// in the last bits often enough to show.  Only the frame equaliser's epilogue calls them (once per frame).
+__device__ __forceinline__ double dm_log64(double x)
+{
+    if (x != x) return x;
+    if (x < 0.0) return __longlong_as_double(0x7ff8000000000000LL);
+    if (x == 0.0) return __longlong_as_double(0xfff0000000000000LL);
+    if (x == __longlong_as_double(0x7ff0000000000000LL)) return x;
+    int k = 0;
+    if (x < 0x1p-1022) { x *= 0x1p54; k = -54; }
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    k += int(b >> 52) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)b);
+    if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; k += 1; }
+    const double f = m - 1.0, s = f / (2.0 + f), z = s * s, w = z * z, dk = double(k);
+    const double t1 = w * (0x1.999999997fa04p-2 + w * (0x1.c71c51d8e78afp-3 + w * 0x1.39a09d078c69fp-3));
+    const double t2 = z * (0x1.5555555555593p-1 + w * (0x1.2492494229359p-2 + w * (0x1.7466496cb03dep-3 + w * 0x1.2f112df3e5244p-3)));
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    return dk * 0x1.62e42fee00000p-1 - ((hfsq - (s * (hfsq + R) + dk * 0x1.a39ef35793c76p-33)) - f);
+}
+__device__ __forceinline__ double dm_log10_64(double x) { return dm_log64(x) * 0x1.bcb7b1526e50ep-2; }
+__device__ __forceinline__ double dm_pow10_64(double y)
+{
+    const double p = y * 0x1.26bb1bbb55516p+1;
+    const double r = dm_exp64(p);
+    if (!(p > -800.0 && p < 800.0) || r == 0.0 || r == __longlong_as_double(0x7ff0000000000000LL)) return r;
+    const double e = __builtin_fma(y, 0x1.26bb1bbb55516p+1, -p) + y * -0x1.f48ad494ea3e9p-53;
+    return __builtin_fma(r, e, r);
+}
+
 // a / b for operands that need none of v_div_scale / v_div_fixup's range handling (no scaling, no
 // special values): the refinement sequence the compiler emits for an IEEE single division, minus those
 // two steps -- same bits, 8 instructions instead of 11 and no VCC hazard.  Only used by dm_log, where

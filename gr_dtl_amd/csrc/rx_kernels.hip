@@ -1064,9 +1064,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
         Welford a = wred[0];
         for (int i = 1; i < int(blockDim.x + 63) / 64; i++) a = welford_merge(a, wred[i], recip, mrec, n_mrec);
         // mpsk_snr_est_simple::snr()/noise(); get_noise() (equalizer.cc:279-287)
-        const double signal_db = 10.0 * log10(fabs(a.mean * a.mean));
-        const double noise_db = 10.0 * log10(2.0 * a.m2 / a.n);
-        stats[blockIdx.x] = { signal_db - noise_db, noise_db, pow(10.0, noise_db / 10.0) };
+        const double signal_db = 10.0 * dm_log10_64(fabs(a.mean * a.mean));
+        const double noise_db = 10.0 * dm_log10_64(2.0 * a.m2 / a.n);
+        stats[blockIdx.x] = { signal_db - noise_db, noise_db, dm_pow10_64(noise_db / 10.0) };
     }
 }
 

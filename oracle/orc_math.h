@@ -80,6 +80,42 @@ static inline double orc_exp(double x)
     return (p * s1) * s2;
 }
 
+/* log(x), log10(x) and 10^y in double, written out like the functions above: the frame equaliser's SNR / noise figures
+ * (mpsk_snr_est_simple::snr() / noise(), equalizer.cc:279-287: 10 log10(.), 10^(./10)) scale every soft bit of a frame, and
+ * the C library's and the GPU library's versions of these functions disagree in the last bits often enough to show.
+ * log: x = m 2^k, m in [sqrt(1/2), sqrt(2)); f = m - 1, s = f / (2 + f); fdlibm's degree-14 odd polynomial in s
+ * (coefficients Lg1..Lg7) and its final assembly; log10 = log * (1 / ln 10) (one more rounding: <= 2 ulp);
+ * 10^y = exp(y ln10) with the product y ln10 carried in two pieces (p + e), exp(p) (1 + e).  Plain IEEE operations in the
+ * order written (no contraction); the GPU executes the same sequence (dtl_math.h). */
+static inline double orc_log(double x)
+{
+    if (x != x) return x;
+    if (x < 0.0) return (double)NAN;
+    if (x == 0.0) return -(double)INFINITY;
+    if (x == (double)INFINITY) return x;
+    int k = 0;
+    if (x < 0x1p-1022) { x *= 0x1p54; k = -54; }            /* subnormal: scale into the normal range */
+    uint64_t b; memcpy(&b, &x, 8);
+    k += (int)(b >> 52) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL; /* m in [1, 2) */
+    double m; memcpy(&m, &b, 8);
+    if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; k += 1; }      /* m in [sqrt(1/2), sqrt(2)) */
+    const double f = m - 1.0, s = f / (2.0 + f), z = s * s, w = z * z, dk = (double)k;
+    const double t1 = w * (0x1.999999997fa04p-2 + w * (0x1.c71c51d8e78afp-3 + w * 0x1.39a09d078c69fp-3));
+    const double t2 = z * (0x1.5555555555593p-1 + w * (0x1.2492494229359p-2 + w * (0x1.7466496cb03dep-3 + w * 0x1.2f112df3e5244p-3)));
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    return dk * 0x1.62e42fee00000p-1 - ((hfsq - (s * (hfsq + R) + dk * 0x1.a39ef35793c76p-33)) - f);
+}
+static inline double orc_log10(double x) { return orc_log(x) * 0x1.bcb7b1526e50ep-2; }
+static inline double orc_pow10(double y)
+{
+    const double p = y * 0x1.26bb1bbb55516p+1;
+    const double r = orc_exp(p);
+    if (!(p > -800.0 && p < 800.0) || r == 0.0 || r == (double)INFINITY) return r; /* overflow / underflow / NaN: no correction term */
+    const double e = ORC_FMA64(y, 0x1.26bb1bbb55516p+1, -p) + y * -0x1.f48ad494ea3e9p-53;
+    return ORC_FMA64(r, e, r);
+}
+
 /* log(x), x >= 0: fdlibm e_logf kernel */
 static inline float orc_logf(float x)
 {

@@ -477,11 +477,11 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
     for (long i = 0; i < total; i++) hard[i] = from_cf(out[i]);
     /* mpsk_snr_est_simple::snr()/noise() and get_noise() (equalizer.cc:279-287) */
     if (snr_out) {
-        double signal_db = 10.0 * log10(fabs(y1 * y1));
-        double noise_db = 10.0 * log10(2.0 * y2 / (counter - 1));
+        double signal_db = 10.0 * orc_log10(fabs(y1 * y1)); /* written-out log10 / 10^x: orc_math.h */
+        double noise_db = 10.0 * orc_log10(2.0 * y2 / (counter - 1));
         snr_out->snr_db = signal_db - noise_db;
         snr_out->noise_db = noise_db;
-        snr_out->noise_lin = pow(10, noise_db / 10.0);
+        snr_out->noise_lin = orc_pow10(noise_db / 10.0);
     }
     /* channel state out, rotated by the frame's accumulated phase (:189-193) */
     float ph = (float)((2.0 * M_PI) * carrier_offset * cp / N * n_sym), sn, cs;

@@ -1,6 +1,7 @@
-"""The kernel-side double exp (dtl_math.h dm_exp64, the LDPC decoder's channel likelihood ratios) returns the bits of the
-oracle's orc_exp on 44 million float arguments and around the range edges: compiled with hipcc at test time, the GPU
-evaluates, the host compares."""
+"""The kernel-side double exp / log10 / 10^y (dtl_math.h dm_exp64: the LDPC decoder's channel likelihood ratios; dm_log10_64,
+dm_pow10_64: the frame's SNR and noise figures) return the bits of the oracle's orc_exp / orc_log10 / orc_pow10 -- exp on
+44 million float arguments and around the range edges, the other two on 6 million random doubles each plus every binade
+and the special values: compiled with hipcc at test time, the GPU evaluates, the host compares."""
 import os
 import subprocess
 
