@@ -1,7 +1,21 @@
-"""Randomised differential test: the HIP chain against the oracle on scenarios drawn from the whole parameter space
-(FFT length, frame length, constellation sequence, Es/N0, carrier frequency offset, sync threshold, frame_detect_bb
-on / off, FEC code, idle gaps, stream cut short), every stage compared as in test_rx_gpu.  Fixed seeds: a failure
-reproduces.  DTL_FUZZ_FIRST / DTL_FUZZ_LAST widen the sweep (default: seeds 0 .. 399, ~15 s)."""
+"""Randomised differential tests: the HIP path against the oracle on seeded random inputs.  Fixed seeds: a failure reproduces.
+
+  test_random_scenario_matches_oracle      whole receive chain; FFT length, frame length, constellation sequence, Es/N0 or
+                                           noise-free, carrier frequency offset, sync threshold, frame_detect_bb on / off,
+                                           FEC code or none, idle gaps, multipath, erased / cut frames, clock slips, stream
+                                           cut short; every stage compared as in test_rx_gpu, then the same stream fed in
+                                           randomly cut calls (bit for bit against the batch call)
+  test_random_scenario_with_carrier_plans  the same with 512 / 1024-point FFTs, random carrier plans (ragged pilot sets,
+                                           frames that hold no whole number of bytes), a wrapping frame counter, the
+                                           decoder's iteration limit and sigma
+  test_random_tx_matches_oracle            the batched transmitter, bit for bit
+  test_random_ldpc_inputs_match_oracle     the decoder alone on any float (inf, NaN, zeros, denormals, shortened words)
+  test_random_demap_inputs_match_oracle    the demapper alone on any float and any noise power
+  test_random_equalizer_inputs_match_oracle  channel estimator and equaliser alone on vectors from no transmitter
+
+Environment: DTL_FUZZ_FIRST / DTL_FUZZ_LAST, DTL_FUZZ_PLAN_FIRST / DTL_FUZZ_PLAN_LAST (seed ranges of the two scenario
+families; defaults 0..399 and 0..239), DTL_FUZZ_AUX (multiplier of the block-level seed counts), DTL_FUZZ_SPECIALS /
+DTL_FUZZ_NO_SPECIALS (special values mixed into the equaliser inputs)."""
 import os
 
 import numpy as np
