@@ -317,7 +317,9 @@ class ofdm_receiver:
         off = self._dev(carr_offset, torch.int32, "header_decode")
         fields = (HeaderFields * max(n, 1))()
         taps_out = torch.empty((n, self.fft_len), dtype=torch.complex64, device=x.device)
-        hdr_bits_len = self.header_len * len(self.occupied_carriers[0])
+        # header symbol i uses carrier set i % n_sets (the kernel's row stride: RxTables.hdr_bits); the sets may differ in size
+        occ = self.occupied_carriers
+        hdr_bits_len = sum(len(occ[i % len(occ)]) for i in range(self.header_len))
         bits = torch.empty((n, hdr_bits_len), dtype=torch.uint8, device=x.device) if want_bits else None
         _lib.check(_lib.lib().dtl_header_decode(self._h, x.data_ptr(), taps.data_ptr(), off.data_ptr(), n, fields,
                                                 bits.data_ptr() if want_bits else None, taps_out.data_ptr(),

@@ -148,9 +148,19 @@ public:
             occ_len.push_back(int32_t(o.size()));
             for (size_t i = 0; i < max_occ; i++) occ_flat.push_back(i < o.size() ? o[i] : 0);
         }
-        for (auto& p : pil) for (int c : p) pil_flat.push_back(c);
+        // pilot sets may differ in size: every set is padded to the largest one with DTL_NO_CARRIER, every pilot-symbol
+        // row with 0 (dtl_rx_cfg reads n_pilot_sets x n_pilots entries)
+        size_t n_pil = 1;
+        for (auto& p : pil) n_pil = std::max(n_pil, p.size());
+        for (auto& row : psym) n_pil = std::max(n_pil, row.size());
+        for (auto& p : pil)
+            for (size_t i = 0; i < n_pil; i++) pil_flat.push_back(i < p.size() ? int32_t(p[i]) : int32_t(DTL_NO_CARRIER));
         std::vector<float> psym_flat;
-        for (auto& row : psym) for (auto& v : row) { psym_flat.push_back(v.real()); psym_flat.push_back(v.imag()); }
+        for (auto& row : psym)
+            for (size_t i = 0; i < n_pil; i++) {
+                psym_flat.push_back(i < row.size() ? row[i].real() : 0.0f);
+                psym_flat.push_back(i < row.size() ? row[i].imag() : 0.0f);
+            }
         // the equaliser block does not look at the synchronisation words; the handle wants well-formed ones
         std::vector<float> sw1(2 * size_t(N), 0.0f), sw2(2 * size_t(N), 0.0f);
         for (int c : occ[0]) {
@@ -169,7 +179,7 @@ public:
         cfg.fft_len = N; cfg.cp_len = cp_len; cfg.frame_length = frame_length;
         cfg.has_fec = equalizer->d_symbols_skipped == 2;   // header_len = symbols_skipped (ofdm_receiver.py:66-68,162)
         cfg.n_occ_sets = int32_t(occ.size()); cfg.max_occ = int32_t(max_occ); cfg.occ_len = occ_len.data(); cfg.occ = occ_flat.data();
-        cfg.n_pilot_sets = int32_t(pil.size()); cfg.n_pilots = int32_t(pil[0].size()); cfg.pilot_carriers = pil_flat.data();
+        cfg.n_pilot_sets = int32_t(pil.size()); cfg.n_pilots = int32_t(n_pil); cfg.pilot_carriers = pil_flat.data();
         cfg.n_pilot_sym_sets = int32_t(psym.size()); cfg.pilot_symbols = psym_flat.data();
         cfg.sync_word1 = sw1.data(); cfg.sync_word2 = sw2.data();
         cfg.sync_threshold = 0.95f; cfg.eq_alpha = equalizer->d_alpha; cfg.max_iterations = 15;

@@ -178,6 +178,9 @@ orc_tbdec* orc_tbdec_new(const orc_ldpc* c, int frame_capacity, int max_bps, int
                          float bp_sigma);
 void orc_tbdec_free(orc_tbdec* d);
 void orc_tbdec_set_arith(orc_tbdec* d, int arith);
+/* test aid: BP iteration count of every codeword the decoder runs (ldpc_dec::decode's *nit, lib/dtl/ldpc_dec.cc:62-71),
+ * appended in decode order; *count keeps counting past cap */
+void orc_tbdec_set_nit_log(orc_tbdec* d, int* log, long cap, long* count);
 /* one frame through ofdm_adaptive_fec_decoder_impl::general_work (:80-217) ->
  * tb_decoder::process_frame (tb_decoder.cc:32-141) -> decode (:143-195) -> on_data_ready.
  * llr: len floats (len = n_syms*bps).  Appends user bits (1/byte) to out (cap out_cap) and TB
@@ -298,6 +301,7 @@ typedef struct {
     uint8_t* user_bytes; long user_bytes_cap; long n_user_bytes;
     orc_tb_rec* tbs; int tbs_cap; int n_tbs;
     int n_frames;
+    int* cw_nit; long cw_nit_cap; long n_cw_nit;   /* iterations per codeword, decode order (optional) */
 } orc_rx_out;
 
 /* whole RX graph of python/dtl/ofdm_receiver.py:59-246 over one sample stream */

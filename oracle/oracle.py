@@ -260,7 +260,7 @@ class RxOut(C.Structure):
                 ("hdr_bits", _P), ("taps", _P), ("user_bits", _P), ("user_bits_cap", C.c_long),
                 ("n_user_bits", C.c_long), ("user_bytes", _P), ("user_bytes_cap", C.c_long),
                 ("n_user_bytes", C.c_long), ("tbs", _P), ("tbs_cap", C.c_int), ("n_tbs", C.c_int),
-                ("n_frames", C.c_int)]
+                ("n_frames", C.c_int), ("cw_nit", _P), ("cw_nit_cap", C.c_long), ("n_cw_nit", C.c_long)]
 
 
 class FrameDetect(C.Structure):
@@ -602,7 +602,7 @@ class TbDecoder:
 
 def rx_stream(cfg, code, iq, feedback=None, max_frames=None, want=("frames",)):
     """Run the whole RX graph.  want: any of eq_hard, eq_soft, soft_syms, llr, hdr_bits, taps,
-    trig, angle.  Returns a dict."""
+    trig, angle, cw (BP iterations of every codeword, decode order).  Returns a dict."""
     iq = np.ascontiguousarray(iq, dtype=c32)
     n = iq.size
     if max_frames is None:
@@ -637,6 +637,9 @@ def rx_stream(cfg, code, iq, feedback=None, max_frames=None, want=("frames",)):
         alloc("hdr_bits", (max_frames, cfg.header_len * cfg.n_data), np.uint8)
     if "taps" in want:
         alloc("taps", (max_frames, N), c32)
+    if "cw" in want and code is not None:
+        cwn = alloc("cw_nit", max_frames * (cap * 4 // code.n + 2) + 8, np.int32)
+        o.cw_nit_cap = cwn.size
     ub = alloc("user_bits", max_frames * cap * 4 + 64, np.uint8)
     o.user_bits_cap = ub.size
     uby = alloc("user_bytes", max_frames * cap // 2 + 64, np.uint8)
@@ -661,9 +664,11 @@ def rx_stream(cfg, code, iq, feedback=None, max_frames=None, want=("frames",)):
         recs.append(d)
     res["frames"] = recs
     for k, a in keep.items():
-        if k in ("user_bits", "user_bytes"):
+        if k in ("user_bits", "user_bytes", "cw_nit"):
             continue
         res[k] = a[:nf] if a.shape[0] == max_frames else a
+    if "cw_nit" in keep:
+        res["cw_nit"] = keep["cw_nit"][:min(o.n_cw_nit, o.cw_nit_cap)].copy()
     res["user_bits"] = ub[:o.n_user_bits].copy()
     res["user_bytes"] = uby[:o.n_user_bytes].copy()
     ntb = min(o.n_tbs, o.tbs_cap)

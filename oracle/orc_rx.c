@@ -75,6 +75,8 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
     long lost_frames = 0;
     orc_tbdec* tbd = NULL;
     if (cfg->has_fec && code) { tbd = orc_tbdec_new(code, cap, 4, cfg->max_it, cfg->bp_sigma); orc_tbdec_set_arith(tbd, cfg->arith); }
+    o->n_cw_nit = 0;
+    if (tbd && o->cw_nit) orc_tbdec_set_nit_log(tbd, o->cw_nit, o->cw_nit_cap, &o->n_cw_nit);
     o->n_frames = 0; o->n_tbs = 0; o->n_user_bits = 0; o->n_user_bytes = 0;
     int rc = 0;
 

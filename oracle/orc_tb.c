@@ -165,7 +165,13 @@ struct orc_tbdec {
     uint8_t* crc_buffer;
     long data_cap;                           /* bits d->data / d->crc_buffer can hold (vectors in the reference) */
     long crc_ok_count, crc_fail_count;
+    int* nit_log; long nit_cap; long* nit_count;   /* optional: iteration count of every codeword, in decode order */
 };
+
+void orc_tbdec_set_nit_log(orc_tbdec* d, int* log, long cap, long* count)
+{
+    d->nit_log = log; d->nit_cap = cap; d->nit_count = count;
+}
 
 orc_tbdec* orc_tbdec_new(const orc_ldpc* c, int frame_capacity, int max_bps, int max_it,
                          float bp_sigma)
@@ -242,6 +248,10 @@ static void tb_decode(orc_tbdec* d, int tb_len, int* avg_it)
         if (k_ > k) memset(&d->data[d_idx + k], 0, k_ - k);
         d_idx += k_;
         sum_it += nit;
+        if (d->nit_log && d->nit_count) {
+            if (*d->nit_count < d->nit_cap) d->nit_log[*d->nit_count] = nit;
+            (*d->nit_count)++;
+        }
     }
     free(cw_out);
     *avg_it = sum_it / tb_len;

@@ -67,6 +67,15 @@ int main(int argc, char** argv)
     for (int i = 0; i < 4; i++) lut.push_back({ mcs_snr[i], { constellation_type_t(mcs_cnst[i]), (unsigned char)mcs_fec[i] } });
     auto feedback = ofdm_adaptive_feedback_decision::make(1, 5, lut, 1);
     auto frame_eq = ofdm_adaptive_frame_equalizer_vcvc::make(equalizer, feedback, cp, "frame_length", "frame_no", true, true, L);
+    {   // pilot sets of different sizes (and a shorter pilot-symbol row): the tables are padded to the largest set
+        auto eq2 = ofdm_adaptive_payload_equalizer::make(
+            N, { constellation_type_t::BPSK }, std::make_shared<ofdm_adaptive_frame_snr_simple>(0.1), { occ },
+            { { -21, -7, 7, 21 }, { -21, 21 } },
+            { { gr_complex(1, 0), gr_complex(1, 0), gr_complex(1, 0), gr_complex(-1, 0) }, { gr_complex(-1, 0), gr_complex(1, 0) } },
+            h, 0.1f, true);
+        auto fe2 = ofdm_adaptive_frame_equalizer_vcvc::make(eq2, feedback, cp, "frame_length", "frame_no", true, true, L);
+        if (!fe2) { std::fprintf(stderr, "ragged pilot sets: no block\n"); return 3; }
+    }
     auto decoders = make_ldpc_decoders({ std::string(argv[1]) });
     const int frame_capacity = L * int(occ.size());
     auto fec_decoder = ofdm_adaptive_fec_decoder::make(decoders, frame_capacity, 4, "packet_len");

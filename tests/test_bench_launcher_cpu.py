@@ -29,3 +29,26 @@ def test_bench_rejects_a_mismatched_world_size():
     out = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert out.returncode != 0
     assert "--gpus 4 but WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+def test_bench_starts_eight_ranks():
+    """configs[3]'s process count: eight ranks rendezvous on 127.0.0.1 and every one reports the world size it joined."""
+    out = _run(["--gpus", "8", "--steps", "1", "--warmup", "0"], {"DTL_BENCH_REHEARSAL_GLOO": "cpu", "OMP_NUM_THREADS": "1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["rank_sum"] == 36.0
+
+
+def test_a_hung_exchange_ends_the_run_with_a_failure_status():
+    """The N > 1 exchange sits behind a watchdog: when it does not come back, rank 0 prints the ONE line it has (with the
+    failure named in extra.root_fed) and the run exits non-zero -- never rc 0."""
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"],
+               {"DTL_BENCH_REHEARSAL_GLOO": "cpu", "DTL_BENCH_REHEARSAL_HANG": "1", "DTL_BENCH_ROOT_FED_TIMEOUT": "3"})
+    assert out.returncode != 0, out.stdout
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert "did not finish" in rec["extra"]["root_fed"]["error"]
+    assert "exiting with status 3" in out.stderr

@@ -117,3 +117,53 @@ def test_c3_full_size_properties(oracle, dtl, cuda):
     ref = oracle.rx_stream(ocfg, code, xp, feedback=oracle_feedback(oracle, cfg, rx))
     assert [(t["tb_no"], t["crc_ok"], t["avg_it"]) for t in resp.tbs] == [(t["tb_no"], t["crc_ok"], t["avg_it"]) for t in ref["tbs"]]
     np.testing.assert_array_equal(resp.payload.cpu().numpy(), ref["user_bytes"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", ["gr_exact", "fast"])
+@pytest.mark.parametrize("esn0", [18.0, 23.0])
+def test_c3_bench_operating_points_match_oracle_codeword_by_codeword(oracle, dtl, cuda, arith, esn0):
+    """The first 1024 frames of the bench's own C3 stream at the operating points the bench quotes: 23 dB (the headline:
+    the link delivers payload) and 18 dB (extra.other_operating_points: the decoder's worst case -- 8.5 iterations per
+    codeword, 40 % of the codewords at the 15-iteration limit, many of them on the saturation / NaN path of the
+    likelihood-ratio arithmetic).  Frames, block records and the iteration count of EVERY codeword against the oracle,
+    in both arithmetics (lib/dtl/ldpc_dec.cc:62-71, tb_decoder.cc:143-195)."""
+    import torch
+    import bench
+    w = dict(bench.WORKLOADS["c3"], esn0_db=esn0)
+    cfg = bench.build_config(dtl, w)
+    cfg.arith = arith
+    rx = dtl.ofdm_receiver(cfg)
+    # the same generator calls as the bench (seed = rank 0): the prefix of the 65 536-frame stream depends on the batch
+    # size only through the user bytes drawn, which are drawn first -- so build the whole stream and cut
+    x, n_frames, n_user, _ = bench.synth_stream(dtl, cfg, w, w["frames"], cuda, seed=0)
+    npre = 100 + 1024 * rx.frame_samples + rx.frame_samples // 2
+    xp = x[:npre].cpu().numpy()
+    del x
+    res = rx.work(torch.from_numpy(xp).to(cuda), want=("cw",))
+    ocfg = oracle.Config(fft_len=cfg.fft_len, cp_len=cfg.cp_len, frame_length=cfg.frame_length, has_fec=True,
+                         sync_threshold=cfg.sync_threshold, occupied_carriers=cfg.occupied_carriers,
+                         pilot_carriers=cfg.pilot_carriers, pilot_symbols=cfg.pilot_symbols,
+                         sync_word1=cfg.sync_word1, sync_word2=cfg.sync_word2, arith={"gr_exact": 0, "fast": 1}[arith])
+    code = oracle.Ldpc(os.path.join(ROOT, "gr_dtl_amd", "codes", "n_0300_k_0152_gap_03.alist"))
+    ref = oracle.rx_stream(ocfg, code, xp, feedback=oracle_feedback(oracle, cfg, rx), want=("frames", "trig", "cw"))
+    np.testing.assert_array_equal(res.raw_triggers, np.nonzero(ref["trig_raw"])[0])
+    np.testing.assert_array_equal(res.fixed_triggers, np.nonzero(ref["trig_fixed"])[0])
+    assert len(res.frames) == ref["n_frames"] >= 1015
+    for f, rf in zip(res.frames, ref["frames"]):
+        assert f["header_ok"] == rf["header_ok"] and f["trigger"] == rf["trigger"]
+        if rf["header_ok"]:
+            assert (f["frame_no"], f["tb_no"], f["tb_offset"], f["payload_len"]) == \
+                (rf["hdr"]["frame_no"], rf["hdr"]["tb_no"], rf["hdr"]["tb_offset"], rf["hdr"]["payload_len"])
+            assert (f["feedback_cnst"], f["lost_frames"]) == (rf["fb_cnst"], rf["lost_frames"])
+            assert f["snr_db"] == pytest.approx(rf["snr_db"], rel=1e-6)
+    assert [(t["tb_no"], t["crc_ok"], t["avg_it"]) for t in res.tbs] == [(t["tb_no"], t["crc_ok"], t["avg_it"]) for t in ref["tbs"]]
+    nit = res.cw_nit.cpu().numpy()
+    assert nit.size == ref["cw_nit"].size > 50000
+    np.testing.assert_array_equal(nit, ref["cw_nit"])
+    np.testing.assert_array_equal(res.payload.cpu().numpy(), ref["user_bytes"])
+    if esn0 == 18.0:
+        # the test must stay at the hard point: a third of the codewords or more run into the iteration limit
+        assert (nit == 15).mean() > 0.3 and nit.mean() > 7.0
+    else:
+        assert (res.tbs["crc_ok"] == 1).mean() > 0.85
