@@ -487,6 +487,38 @@ int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers,
     return DTL_OK;
 }
 
+int dtl_fix_sync_chunked(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, const int64_t* buf_ends,
+                         int64_t n_bufs, const int64_t* horizons, int64_t n_horizons, int64_t* out, int64_t out_cap,
+                         int64_t* n_out)
+{
+    if (!n_out || (n_triggers && !triggers) || (n_bufs && !buf_ends) || (n_horizons && !horizons)) return DTL_ERR_INVALID_ARG;
+    dtl::FrameDetectState st;
+    st.frame_len = frame_len;
+    std::vector<int64_t> res;
+    int64_t begin = 0, ti = 0, hi = 0;
+    for (int64_t b = 0; b < n_bufs; b++) {
+        const int64_t end = buf_ends[b];
+        if (end < begin) return DTL_ERR_INVALID_ARG;
+        dtl::FixSyncRun run(st);
+        // the triggers of this buffer, piece by piece: everything in front of the next horizon, then the horizon itself
+        while (hi < n_horizons && horizons[hi] <= begin) hi++;
+        for (; hi < n_horizons && horizons[hi] < end; hi++) {
+            std::vector<int64_t> piece;
+            while (ti < n_triggers && triggers[ti] < horizons[hi]) piece.push_back(triggers[ti++] - begin);
+            run.feed(piece.data(), piece.size(), horizons[hi] - begin);
+        }
+        std::vector<int64_t> rest;
+        while (ti < n_triggers && triggers[ti] < end) rest.push_back(triggers[ti++] - begin);
+        run.feed(rest.data(), rest.size(), 0);
+        for (int64_t p : run.finish(end - begin)) res.push_back(p + begin);
+        begin = end;
+    }
+    *n_out = int64_t(res.size());
+    if (int64_t(res.size()) > out_cap) return DTL_ERR_CAPACITY;
+    std::copy(res.begin(), res.end(), out);
+    return DTL_OK;
+}
+
 int dtl_plateau_detect(const float* metric, int64_t n, float thr, int32_t max_len, int64_t* out, int64_t out_cap,
                        int64_t* n_out)
 {

@@ -17,6 +17,9 @@
 
 #include "dtl_math.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace dtl {
@@ -849,20 +852,80 @@ __device__ __forceinline__ Welford welford_merge(Welford a, Welford b, const dou
 // FREQ_IN == true serves the per-block entry point dtl_equalize_frames: `iq` then holds, per frame, the L x N
 // frequency-domain vectors the reference's frame equaliser block receives from fft_vcc (shifted, DC at N/2) and the
 // batches are copied from there instead of being cut out of the IQ stream and transformed.
-template <bool STAGED, bool FREQ_IN = false>
-__global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
+// DEMAP >= 0 (opt-in, see payload_is_fused; DEMAP = MODE of soft_demap_symbol): the soft demapper runs in
+// this kernel's epilogue instead of a kernel of its own, and the equalised data symbols never cross HBM.  The demapper
+// needs the frame's FINAL noise estimate, so the frame's equalised data symbols stay on chip until the Welford merge
+// has finished: the first `rho0 + 1` OFDM symbols parked in LDS in serializer order (as many as leave room for the four
+// workgroups per CU the register budget allows), the rest in REGISTERS of the lane that equalised them (2 VGPRs per
+// symbol, kEqRegSlots slots: slot = source row - rho0, a wave-uniform index whatever the lane's own lag; rho0 a multiple
+// of 4).  Then ALL N lanes pick symbols in serializer order (lane == data symbol, not carrier: no lane idles on a
+// pilot or an unused carrier) -- from the parked rows directly, from the registers through the (now free) FFT scratch in
+// batches of four OFDM symbols -- and store their soft bits at llr_off[frame].  The price is registers: four workgroups
+// per CU instead of five for the sequential equaliser recursion; the gain is that the demapper's arithmetic fills issue
+// slots the recursion leaves idle, and 8 B per data symbol less in each direction.
+constexpr int kEqRegSlots = 8;
+constexpr int kEqFusedMaxSyms = 28;             // frame_length served by the fused form
+
+// keep[4 B + OFF + j] <-> v[j], j = 0 .. J-1, for a wave-uniform B, written as selects over STATIC register indices
+// (a switch over B is turned into one indexed access by the optimiser, which sends the array to scratch memory)
+template <bool STORE, int OFF, int J>
+__device__ __forceinline__ void keep_window(int B, float (&kr)[kEqRegSlots], float (&ki)[kEqRegSlots], cf32 (&v)[J])
+{
+    if constexpr (STORE) {
+#pragma unroll
+        for (int s = 0; s < kEqRegSlots; s++) {
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                // slot s takes v[j] when 4 B + OFF + j == s
+                if ((s - OFF - j) % 4 == 0 && s - OFF - j >= 0) {
+                    const bool hit = B == (s - OFF - j) / 4;
+                    kr[s] = hit ? v[j].re : kr[s];
+                    ki[s] = hit ? v[j].im : ki[s];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            float re = 0.0f, im = 0.0f;
+#pragma unroll
+            for (int s = 0; s < kEqRegSlots; s++) {
+                if ((s - OFF - j) % 4 == 0 && s - OFF - j >= 0) {
+                    const bool hit = B == (s - OFF - j) / 4;
+                    re = hit ? kr[s] : re;
+                    im = hit ? ki[s] : im;
+                }
+            }
+            v[j] = cf32{ re, im };
+        }
+    }
+}
+
+template <bool STAGED, bool FREQ_IN = false, int DEMAP = -1>
+__global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4 : 5))) void frame_eq_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
                                 const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
                                 int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
                                 cf32* __restrict__ eq_hard, cf32* __restrict__ eq_soft,
-                                cf32* __restrict__ soft_syms)
+                                cf32* __restrict__ soft_syms, const uint32_t* __restrict__ llr_off = nullptr,
+                                float* __restrict__ llr_out = nullptr, int rho0 = 0)
 {
+    static_assert(DEMAP < 0 || (STAGED && !FREQ_IN), "the fused demapper belongs to the staged receive-path form");
+    constexpr bool FUSED = DEMAP >= 0;
     extern __shared__ unsigned char smem_raw[];
     const int N = t.fft_len, L = t.frame_length, tid = threadIdx.x, h = t.header_len;
     cf32* buf = reinterpret_cast<cf32*>(smem_raw);    // 4 x N : FFT scratch (four symbols per batch)
     Welford* wred = reinterpret_cast<Welford*>(buf + 4 * N); // blockDim/64 partials
     cf32* tw = reinterpret_cast<cf32*>(wred + (N + 63) / 64); // N per-pass twiddles
     [[maybe_unused]] cf32* st_soft = tw + N;          // STAGED: 4 x N data symbols of the running batch (lane k: column k)
-    [[maybe_unused]] cf32* st_pil = st_soft + 4 * N;  // STAGED: 4 x N pilot values of the lane's next four steps
+    [[maybe_unused]] cf32* st_pil = FUSED ? tw + N : st_soft + 4 * N;  // STAGED: 4 x N pilot values of the lane's next four steps
+    [[maybe_unused]] int16_t* s_occ = reinterpret_cast<int16_t*>(st_pil + 4 * N); // FUSED: shifted position of data carrier r
+    [[maybe_unused]] cf32* park = reinterpret_cast<cf32*>(s_occ + ((N + 3) & ~3));  // FUSED: (rho0 + 1) x data carriers, serializer order
+    [[maybe_unused]] float keep_re[kEqRegSlots], keep_im[kEqRegSlots];
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int e = 0; e < kEqRegSlots; e++) keep_re[e] = keep_im[e] = 0.0f;
+    }
+    [[maybe_unused]] const int n_lds = rho0 + 1;      // FUSED: destination symbols i < n_lds are parked in LDS
     tw[tid] = t.twiddle[tid];
 
     const FrameDesc fd = frames[blockIdx.x];
@@ -883,6 +946,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     // that chain must be short.  This frame's constellation goes to LDS; whether carrier k is a pilot (per pilot
     // set) becomes a bit mask in a register, and the pilot value of a step is requested before the first division.
     __shared__ cf32 s_pts[16];
+    [[maybe_unused]] __shared__ float s_np[2];        // FUSED: the frame's npwr and its reciprocal for the demapper
     if (tid < 16) s_pts[tid] = t.cnst_pts[fd.cnst * 16 + tid];
     const cf32* pts = s_pts;
     const bool pilot_bits_ok = t.n_pilot_sets <= 32;
@@ -896,10 +960,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     // a lane's own sample count, at most L + 1 of them: LDS) or known one step ahead (the pilot value, and rank /
     // length when the carrier sets rotate: requested during the previous step).  The three set indices advance by
     // one per symbol and wrap: counters, not modulo operations.
-    __shared__ double s_recip[kEqRecipLds];
-    const bool recip_in_lds = L + 2 <= kEqRecipLds;
+    // (the fused form serves frames of at most kEqFusedMaxSyms symbols and spends its LDS on parked data symbols)
+    constexpr int kRecipHere = FUSED ? kEqFusedMaxSyms + 4 : kEqRecipLds;
+    __shared__ double s_recip[kRecipHere];
+    const bool recip_in_lds = L + 2 <= kRecipHere;
     if (recip_in_lds)
         for (int e = tid; e < L + 2; e += blockDim.x) s_recip[e] = recip[e];
+    if constexpr (FUSED) {                            // one data-carrier set (STAGED): ofdm_serializer_vcc's order
+        const int set = 1 % t.n_occ_sets, n_occ = t.occ_len[set];
+        for (int e = tid; e < n_occ; e += blockDim.x) s_occ[e] = t.occ_idx[set * t.max_occ + e];
+    }
     int pilot_carr_set = t.n_pilot_sets ? h % t.n_pilot_sets : 0;
     int pset = h % t.n_pilot_sym_sets;                // pilot symbol set of destination symbol 0
     int oset = 1 % t.n_occ_sets;                      // ofdm_serializer_vcc: symbols_skipped = 1
@@ -917,7 +987,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     [[maybe_unused]] int staged = 0, staged_base = 0; // STAGED: steps run since stage_begin, q_base at stage_begin
 
     // frame_equalize for destination symbol i of this carrier (ofdm_adaptive_equalizer.cc:217-268)
-    auto eq_step = [&](int i, cf32 y) {
+    auto eq_step = [&](int i, cf32 y) -> cf32 {
         const bool is_pilot = STAGED ? (t.n_pilot_sets && ((pilot_bits >> pilot_carr_set) & 1u) != 0) : pilot_here(pilot_carr_set);
         cf32 hard_v = y, soft_v = { 0.0f, 0.0f };
         // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
@@ -962,12 +1032,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
             hard_v = ref;
         }
         if (STAGED) {
-            st_soft[staged * N + k] = soft_v;         // stored by stage_end
+            if (!FUSED) st_soft[staged * N + k] = soft_v;         // stored by stage_end
+            else if (occ_r >= 0 && i < n_lds) park[i * occ_n + occ_r] = soft_v; // (later symbols: kept in registers by the caller)
             staged++;
             q_base += occ_n;
             pset = pset + 1 == t.n_pilot_sym_sets ? 0 : pset + 1;
             pilot_carr_set = t.n_pilot_sets ? (pilot_carr_set + 1 == t.n_pilot_sets ? 0 : pilot_carr_set + 1) : 0;
-            return;
+            return soft_v;
         }
         if (hard_row) hard_row[i * N + k] = hard_v;
         if (soft_row) soft_row[i * N + k] = soft_v;
@@ -984,6 +1055,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
             if (pilot_here(pilot_carr_set)) pilot_next = t.pilot_val[pset * N + k];
             if (!one_occ_set) { occ_r = t.occ_rank[oset * N + k]; occ_n = t.occ_len[oset]; }
         }
+        return soft_v;
     };
 
     // STAGED: pilot values of the lane's next four steps (loads without a branch between them: one wait for all)
@@ -1006,7 +1078,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     // STAGED: the data symbols of the steps just run, in serializer order (symbols_skipped = 1: data carrier r of the
     // u-th of these steps is symbol staged_base + u occ_n + r)
     auto stage_end = [&]() {
-        if (!STAGED) return;
+        if (!STAGED || FUSED) return;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int idx = staged_base + u * occ_n + occ_r;
@@ -1015,7 +1087,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
     };
 
     __syncthreads();                                  // s_pts, tw
-    if (lag < 0) { stage_begin(); eq_step(0, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row -1: the zero fill of the shift
+    [[maybe_unused]] cf32 post_v = { 0.0f, 0.0f };    // FUSED: the symbol equalised from the zero row behind the frame (lag > 0)
+    if (lag < 0) { // its source would be row -1: the zero fill of the shift
+        stage_begin();
+        eq_step(0, cf32{ 0.0f, 0.0f });              // FUSED: destination 0 is always among the parked rows
+        stage_end();
+    }
     for (int i0 = 0; i0 < L; i0 += 4) {
         const int nb = min(4, L - i0);
         if constexpr (FREQ_IN) {
@@ -1026,6 +1103,22 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
             load_and_fft4<DTL_ABLATE>(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
         }
         stage_begin();
+        if constexpr (FUSED) {
+            // the four steps written out: their results go to the register slots of source rows i0 .. i0 + 3
+            cf32 sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                sv[u] = cf32{ 0.0f, 0.0f };
+                const int i = i0 + u - lag;
+                if (u < nb && i >= 0 && i < L) {
+                    const cf32 v = buf[u * N + bin];
+                    cf32 pc = { 1.0f, -0.0f };
+                    if (off != 0) pc = expj(float(-(2.0 * kPi) * off * t.cp_len / N * (i + 1)));
+                    sv[u] = eq_step(i, cmul(v, pc));
+                }
+            }
+            if (i0 >= rho0) keep_window<true, 0, 4>((i0 - rho0) >> 2, keep_re, keep_im, sv);
+        } else
         for (int u = 0; u < nb; u++) {
             const int i = i0 + u - lag;               // destination symbol fed by source row i0 + u
             if (i >= 0 && i < L) {
@@ -1039,7 +1132,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
         stage_end();
         __syncthreads();                              // the next batch overwrites the scratch rows
     }
-    if (lag > 0) { stage_begin(); eq_step(L - 1, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row L
+    if (lag > 0) { stage_begin(); post_v = eq_step(L - 1, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row L
 
     // combine the per-carrier Welford states (Chan); double, fixed tree order.  The reciprocals of the merged counts
     // (at most L x pilots-per-set of them) go to the FFT scratch first, which is free now.
@@ -1066,7 +1159,71 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) void frame_eq_kernel(RxTab
         // mpsk_snr_est_simple::snr()/noise(); get_noise() (equalizer.cc:279-287)
         const double signal_db = 10.0 * dm_log10_64(fabs(a.mean * a.mean));
         const double noise_db = 10.0 * dm_log10_64(2.0 * a.m2 / a.n);
-        stats[blockIdx.x] = { signal_db - noise_db, noise_db, dm_pow10_64(noise_db / 10.0) };
+        const double noise_lin = dm_pow10_64(noise_db / 10.0);
+        stats[blockIdx.x] = { signal_db - noise_db, noise_db, noise_lin };
+        if constexpr (FUSED) {
+            // sigma = sqrt(noise) passed as npwr (soft_cf_impl.cc:101,144) and its correctly rounded single reciprocal
+            const float npwr = float(sqrt(noise_lin));
+            s_np[0] = npwr;
+            s_np[1] = float(1.0 / double(npwr));
+        }
+    }
+    if constexpr (FUSED) {
+        // ---- ofdm_serializer_vcc + ofdm_adaptive_constellation_soft_cf on the symbols this workgroup kept
+        __syncthreads();                              // s_np, parked rows; the reciprocal table in the scratch rows is dead
+        const float npwr = s_np[0], rinv = s_np[1];
+        const int n_syms = fd.n_syms;                 // payload == 0: frame dropped after the equaliser (:218,254)
+        const int bps = fd.cnst == 4 ? 4 : fd.cnst;
+        const int n_occ = occ_n;                      // data carriers per OFDM symbol (one set)
+        const uint32_t base = llr_off[blockIdx.x];
+        float* const llr_frame = llr_out + size_t(base);
+        cf32* const soft_out_f = soft_syms ? soft_syms + size_t(blockIdx.x) * t.frame_capacity : nullptr;
+        auto demap_one = [&](int q, cf32 sy) {
+            if (soft_out_f) soft_out_f[q] = sy;
+            float* dst = llr_frame + size_t(q) * bps;
+            float o[4];
+            switch (bps) {
+            case 1: soft_demap_symbol<1, DEMAP>(sy, pts, npwr, rinv, o); dst[0] = o[0]; break;
+            case 2:
+                soft_demap_symbol<2, DEMAP>(sy, pts, npwr, rinv, o);
+                if ((base & 1u) == 0) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+                else { dst[0] = o[0]; dst[1] = o[1]; }
+                break;
+            case 3: soft_demap_symbol<3, DEMAP>(sy, pts, npwr, rinv, o); dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; break;
+            default:
+                soft_demap_symbol<4, DEMAP>(sy, pts, npwr, rinv, o);
+                if ((base & 3u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
+                break;
+            }
+        };
+        // the parked rows: already in serializer order
+        const int n_parked = min(n_syms, min(n_lds, L) * n_occ);
+        for (int q = tid; q < n_parked; q += N) demap_one(q, park[q]);
+        // the rows kept in registers, four OFDM symbols at a time through the scratch rows: destination symbol
+        // rho0 + 4 B + u of this carrier sits in slot 4 B + u + lag - 1 (slot kEqRegSlots: the zero row behind the frame)
+        for (int B = 0; rho0 + 4 * B < L && (rho0 + 4 * B + 4 > n_lds) && (rho0 + 4 * B) * n_occ < n_syms; B++) {
+            const int i_first = rho0 + 4 * B, nb = min(4, L - i_first);
+            cf32 w6[6];
+            keep_window<false, -1, 6>(B, keep_re, keep_im, w6);
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int u = j - lag - 1;
+                if (u >= 0 && u < nb && i_first + u >= n_lds) {
+                    cf32 v = w6[j];
+                    if (4 * B - 1 + j == L - rho0) v = post_v;   // the slot behind the last source row
+                    buf[u * N + k] = v;
+                }
+            }
+            __syncthreads();
+            const int n_here = nb * n_occ;
+            for (int qq = tid; qq < n_here; qq += N) {
+                const int u = (qq >= n_occ ? 1 : 0) + (qq >= 2 * n_occ ? 1 : 0) + (qq >= 3 * n_occ ? 1 : 0);
+                const int q = i_first * n_occ + qq;   // index in the frame's symbol stream
+                if (i_first + u >= n_lds && q < n_syms) demap_one(q, buf[u * N + s_occ[qq - u * n_occ]]);
+            }
+            __syncthreads();                          // the next batch overwrites the rows
+        }
     }
 }
 
@@ -1503,7 +1660,7 @@ size_t header_lds_bytes(const RxTables& t)
     return (b + 15) & ~size_t(15);
 }
 
-static size_t frame_eq_lds_bytes(const RxTables& t, bool staged);
+static size_t frame_eq_lds_bytes(const RxTables& t, bool staged, bool fused, int rho0 = 0);
 
 int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate* cands, int n_cand,
                   const CfoSegment* segs, int n_segs, HeaderRec* recs, cf32* taps, uint8_t* hdr_bits,
@@ -1547,47 +1704,106 @@ int launch_frame_eq_stage(const RxTables& t, const cf32* freq, const FrameDesc* 
                           FrameStat* stats, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, hipStream_t st)
 {
     if (n_frames <= 0) return DTL_OK;
-    const size_t lds = frame_eq_lds_bytes(t, false);
+    const size_t lds = frame_eq_lds_bytes(t, false, false);
     if (lds > 64 * 1024) { set_last_error("frame equaliser: FFT scratch does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL((frame_eq_kernel<false, true>), dim3(n_frames), dim3(t.fft_len), lds, st, t, freq, int64_t(0), frames,
-                       nullptr, 0, taps, stats, eq_hard, eq_soft, soft_syms);
+                       nullptr, 0, taps, stats, eq_hard, eq_soft, soft_syms, nullptr, nullptr, 0);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }
 
-static size_t frame_eq_lds_bytes(const RxTables& t, bool staged)
+static size_t frame_eq_lds_bytes(const RxTables& t, bool staged, bool fused, int rho0)
 {
     size_t b = size_t(4 * t.fft_len) * sizeof(cf32) + size_t((t.fft_len + 63) / 64) * sizeof(Welford) +
                size_t(t.fft_len) * sizeof(cf32);
-    if (staged) b += size_t(8 * t.fft_len) * sizeof(cf32); // two 4 x N arrays: parked data symbols, pilot values
+    if (staged) b += size_t((fused ? 4 : 8) * t.fft_len) * sizeof(cf32); // 4 x N arrays: pilot values (+ parked data symbols)
+    if (fused) {
+        b += size_t((t.fft_len + 3) & ~3) * sizeof(int16_t);              // data-carrier positions in serializer order
+        b += size_t(rho0 + 1) * size_t(t.max_occ) * sizeof(cf32);         // parked rows
+    }
     return (b + 15) & ~size_t(15);
 }
 
-size_t payload_lds_bytes(const RxTables& t) { return frame_eq_lds_bytes(t, false); }
+size_t payload_lds_bytes(const RxTables& t) { return frame_eq_lds_bytes(t, false, false); }
+
+static bool payload_staged(const RxTables& t, bool eq_rows)
+{
+    // the staged form (no global memory inside an equaliser step) serves the usual configuration when its LDS fits
+    return t.n_occ_sets == 1 && t.n_pilot_sets <= 32 && !eq_rows && frame_eq_lds_bytes(t, true, false) <= 64 * 1024;
+}
+
+// Fused phase B: how many of the frame's OFDM symbols are parked in LDS (rho0 + 1, rho0 a multiple of 4) -- as many as
+// leave the CU's 160 KB of LDS to the four workgroups per SIMD wave slot the kernel's registers allow; the remaining
+// L - rho0 source rows (at most kEqRegSlots) stay in registers.  -1: the frame does not fit (two-kernel form).
+static int fused_rho0(const RxTables& t)
+{
+    const int L = t.frame_length;
+    if (L > kEqFusedMaxSyms) return -1;
+    const size_t waves = size_t((t.fft_len + 63) / 64);
+    size_t budget = std::min<size_t>(64 * 1024, size_t(160 * 1024) * waves / 16);
+    if (const char* e = getenv("DTL_FUSED_LDS_BUDGET")) budget = size_t(atol(e));   // experiments
+    const size_t fixed = frame_eq_lds_bytes(t, true, true, -1) + 640 /* static: constellation, reciprocals */ + 1024 /* slack */;
+    const size_t per_row = size_t(t.max_occ) * sizeof(cf32);
+    if (budget < fixed + per_row) return -1;
+    const int rows = int((budget - fixed) / per_row);
+    int rho0 = ((rows - 1) / 4) * 4;                  // rho0 + 1 <= rows
+    if (rho0 >= L) rho0 = (L + 3) & ~3;               // everything parked
+    if (L - rho0 > kEqRegSlots) return -1;
+    return rho0;
+}
+
+// Does phase B run as ONE kernel (frame equaliser with the soft demapper in its epilogue)?  Opt-in
+// (DTL_RX_FUSED_PHASE_B=1) for FEC configurations whose frames fit on chip: measured on C3 the fused kernel moves 4.5 GB
+// less per step through HBM but takes 3 % longer than the two kernels it replaces -- both are bound by the VALU issue
+// rate, not by latency or memory, so there are no idle slots for the demapper to fill (DESIGN.md 10,
+// profiles/r03/fused_eq_demap_*).  tests/test_fused_phase_b_gpu.py holds the two forms bit-identical.
+bool payload_is_fused(const RxTables& t, bool eq_rows)
+{
+    const char* e = getenv("DTL_RX_FUSED_PHASE_B");
+    if (!e || e[0] != '1') return false;
+    return t.has_fec && payload_staged(t, eq_rows) && fused_rho0(t) >= 0;
+}
 
 // phase B: frame equaliser (FFT + decision-directed one-tap equaliser + SNR estimate) -> soft demapper (FEC) or
-// hard demapper + packer + CRC (no FEC); the equalised data symbols are handed over in `soft_syms` (n_frames x capacity)
+// hard demapper + packer + CRC (no FEC).  Fused form: one kernel, `soft_syms` written only when the caller wants the
+// serializer's stream (soft_syms_wanted); two-kernel form: the equalised data symbols are handed over in `soft_syms`
+// (n_frames x capacity), which must exist.
 int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
                    const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
-                   const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms,
+                   const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
                    uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st)
 {
     if (n_frames <= 0) return DTL_OK;
-    if (!soft_syms) { set_last_error("payload: no buffer for the equalised symbols"); return DTL_ERR_INVALID_ARG; }
-    // the staged form (no global memory inside an equaliser step) serves the usual configuration when its LDS fits
-    const bool staged = t.n_occ_sets == 1 && t.n_pilot_sets <= 32 && !eq_hard && !eq_soft &&
-                        frame_eq_lds_bytes(t, true) <= 64 * 1024;
-    const size_t lds = frame_eq_lds_bytes(t, staged);
+    const bool eq_rows = eq_hard || eq_soft;
+    const bool staged = payload_staged(t, eq_rows);
+    const bool fused = payload_is_fused(t, eq_rows);
+    const int rho0 = fused ? fused_rho0(t) : 0;
+    if (!fused && !soft_syms) { set_last_error("payload: no buffer for the equalised symbols"); return DTL_ERR_INVALID_ARG; }
+    const size_t lds = frame_eq_lds_bytes(t, staged, fused, rho0);
     if (lds > 64 * 1024) { set_last_error("payload kernel: FFT scratch does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
+    const int mode = demap_mode(t.llr_dist_mode);
+    if (fused) {
+        cf32* ss = soft_syms_wanted ? soft_syms : nullptr;
+        if (mode == 1)
+            hipLaunchKernelGGL((frame_eq_kernel<true, false, 1>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
+                               taps, stats, eq_hard, eq_soft, ss, llr_off, llr, rho0);
+        else if (mode == 2)
+            hipLaunchKernelGGL((frame_eq_kernel<true, false, 2>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
+                               taps, stats, eq_hard, eq_soft, ss, llr_off, llr, rho0);
+        else
+            hipLaunchKernelGGL((frame_eq_kernel<true, false, 0>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
+                               taps, stats, eq_hard, eq_soft, ss, llr_off, llr, rho0);
+        DTL_HIP_CHECK(hipGetLastError());
+        return DTL_OK;
+    }
     if (staged)
         hipLaunchKernelGGL(frame_eq_kernel<true>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
-                           stats, eq_hard, eq_soft, soft_syms);
+                           stats, eq_hard, eq_soft, soft_syms, nullptr, nullptr, 0);
     else
         hipLaunchKernelGGL(frame_eq_kernel<false>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
-                           stats, eq_hard, eq_soft, soft_syms);
+                           stats, eq_hard, eq_soft, soft_syms, nullptr, nullptr, 0);
     if (t.has_fec) {
         const dim3 grid(n_frames, (t.frame_capacity + 255) / 256);
-        const int mode = demap_mode(t.llr_dist_mode);
         if (mode == 1) hipLaunchKernelGGL(demap_kernel<1>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
         else if (mode == 2) hipLaunchKernelGGL(demap_kernel<2>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
         else hipLaunchKernelGGL(demap_kernel<0>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);

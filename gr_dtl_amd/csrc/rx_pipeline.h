@@ -52,6 +52,28 @@ struct FrameDetectState {
 };
 // sparse-trigger form of ofdm_adaptive_frame_detect_bb_impl::fix_sync (one buffer of `len` items)
 std::vector<int64_t> fix_sync_sparse(FrameDetectState& s, const std::vector<int64_t>& triggers, int64_t len);
+// the same walk, resumable: triggers are fed as they become known (ascending; complete below `horizon`), the buffer's
+// length is given last.  feed()s + finish(len) == fix_sync_sparse(all triggers, len), state included.
+class FixSyncRun {
+public:
+    explicit FixSyncRun(FrameDetectState& st);
+    void feed(const int64_t* trig, size_t n, int64_t horizon);
+    std::vector<int64_t> finish(int64_t len);
+    int64_t position() const { return i; }   // the walk has dealt with everything in front of this item
+private:
+    static constexpr int64_t kInf = INT64_MAX;
+    void advance(bool final, int64_t len);
+    void reseat(int64_t pos);
+    int64_t next_set(int64_t pos);
+    void insert_added(int64_t pos);
+    void erase_at(int64_t pos);
+    FrameDetectState& s;
+    std::vector<int64_t> triggers, added;    // added: kept sorted
+    std::vector<uint8_t> erased;
+    size_t cur = 0, cur_add = 0;
+    int64_t i = 0, index = 0, last_trigger_index = 0, horizon = 0;
+    bool trigger_found = false;
+};
 // plateau_detector_fb(max_len, threshold) from the metric's threshold crossings
 std::vector<int64_t> plateau_from_edges(std::vector<unsigned long long> edges, int64_t n, int max_len);
 

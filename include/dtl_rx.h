@@ -356,6 +356,13 @@ int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);
  * ofdm_adaptive_frame_detect_bb_impl::fix_sync on a sparse trigger list */
 int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, int64_t stream_len,
                  int64_t* out, int64_t out_cap, int64_t* n_out);
+/* the same over consecutive work() buffers (buffer b holds items [buf_ends[b-1], buf_ends[b]) of one trigger stream;
+ * the block's state carries over), with every buffer's triggers handed to the walk piecewise: `horizons` (ascending
+ * absolute positions) are the points up to which the trigger list is declared complete before the buffer's length is
+ * known -- the resumable form the receive path runs under its sync kernels.  Must equal the one-shot form. */
+int dtl_fix_sync_chunked(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, const int64_t* buf_ends,
+                         int64_t n_bufs, const int64_t* horizons, int64_t n_horizons, int64_t* out, int64_t out_cap,
+                         int64_t* n_out);
 /* GR plateau_detector_fb(max_len, threshold) over a HOST metric array (the same host routine
  * the pipeline runs on the kernel's threshold crossings) */
 int dtl_plateau_detect(const float* metric_host, int64_t n, float threshold, int32_t max_len,

@@ -282,3 +282,51 @@ def test_transport_block_bookkeeping_matches_oracle(oracle, dtl):
         compared += 1
         blocks += len(got)
     assert compared >= 30 and blocks >= 300, (compared, blocks)
+
+
+def test_fix_sync_fed_piecewise_equals_one_shot(oracle, dtl):
+    """The receive path hands frame_detect_bb's walk the triggers range by range (under the sync kernels) and the
+    buffer's length last (FixSyncRun): any split must give the one-shot result, over consecutive buffers too (the block's
+    state -- in_sync, remainder, error counters -- carries over), and the one-shot result is the dense reference form's."""
+    L = dtl._lib.lib()
+    L.dtl_fix_sync_chunked.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+
+    def chunked(FL, pos, ends, horizons):
+        t = np.ascontiguousarray(pos, dtype=np.int64)
+        e = np.ascontiguousarray(ends, dtype=np.int64)
+        h = np.ascontiguousarray(sorted(horizons), dtype=np.int64)
+        out = np.zeros(t.size * 3 + int(e[-1]) // max(FL, 1) + 64, dtype=np.int64)
+        n_out = C.c_int64(0)
+        assert L.dtl_fix_sync_chunked(FL, t.ctypes.data, t.size, e.ctypes.data, e.size, h.ctypes.data, h.size,
+                                      out.ctypes.data, out.size, C.byref(n_out)) == 0
+        return out[:n_out.value]
+    rng = np.random.default_rng(11)
+    for case in range(300):
+        FL = int(rng.choice([1920, 1920, 640, 7680]))
+        nfr = int(rng.integers(5, 120))
+        pos = int(rng.integers(0, FL)) + FL * np.arange(nfr)
+        if case % 4:
+            pos = pos + rng.choice([0, 0, 0, 0, 0, 1, -1, 1, 2, -3, 5, -7, 9, 12, 30], nfr)
+        if case % 3 == 0:       # a clock that drifts by a sample now and then (accumulated error -> corrections)
+            pos = pos + np.cumsum(rng.random(nfr) < 0.15)
+        pos = pos[rng.random(nfr) > (0.2 if case % 2 else 0.0)]                               # missed detections
+        pos = np.unique(np.concatenate([pos, rng.integers(0, FL * nfr, int(rng.integers(0, 5)))]))  # false alarms
+        n = FL * nfr + int(rng.integers(0, 2 * FL))
+        pos = pos[(pos >= 0) & (pos < n)]
+        # one buffer or several (cuts anywhere, also right behind a trigger and within the reach of a deadline)
+        n_bufs = int(rng.choice([1, 1, 2, 3, 6]))
+        ends = sorted(set(int(v) for v in rng.integers(1, n, n_bufs - 1))) + [n]
+        one_shot = chunked(FL, pos, ends, [])
+        for trial in range(3):
+            nh = int(rng.choice([1, 3, 8, 40]))
+            horizons = [int(v) for v in rng.integers(0, n + 1, nh)]
+            if pos.size and trial == 1:
+                horizons += [int(p) + int(d) for p, d in zip(rng.choice(pos, 5), rng.integers(-12, 13, 5))]
+            got = chunked(FL, pos, ends, [h for h in horizons if 0 <= h <= n])
+            np.testing.assert_array_equal(got, one_shot, err_msg="case %d trial %d" % (case, trial))
+        if n_bufs == 1:
+            dense = np.zeros(n, np.uint8)
+            dense[pos] = 1
+            ref, _ = oracle.fix_sync(FL, dense)
+            np.testing.assert_array_equal(one_shot, np.nonzero(ref)[0], err_msg="case %d" % case)
