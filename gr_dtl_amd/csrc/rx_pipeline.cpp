@@ -18,7 +18,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
+#include <thread>
 
 namespace dtl {
 
@@ -519,6 +522,7 @@ Receiver::Receiver() : ss_(std::make_unique<StreamState>())
 {
     // tests lower the threshold so that small streams take the pipelined (four ranges, early header launches) path
     if (const char* e = getenv("DTL_RX_SPLIT_MIN")) split_min_ = std::max<int64_t>(1, atoll(e));
+    if (const char* e = getenv("DTL_RX_SYNC_RANGES")) sync_ranges_ = std::min(16, std::max(1, atoi(e)));
 }
 
 void Receiver::reset_stream()
@@ -909,7 +913,10 @@ int Receiver::stage_sync(Call& c)
     unsigned n_edges_total = 0;
     {
         const int64_t mb0 = B - A;
-        const int n_sc = n >= split_min_ ? 4 : 1;
+        // eight ranges: what the host does for a range (sort, plateau detector, frame_detect_bb walk, oscillator phases,
+        // queueing the range's header kernel) takes about as long as the range's sync kernel, so the device works through
+        // sync and header kernels back to back and only the LAST range's host share (an eighth of the call's) is exposed
+        const int n_sc = n >= split_min_ ? sync_ranges_ : 1;
         struct Range { int64_t mb, me; unsigned max_edges, guess; size_t off; };
         std::vector<Range> rg;
         size_t edge_slots = 0;
@@ -926,12 +933,12 @@ int Receiver::stage_sync(Call& c)
         }
         if (!rg.empty()) {
             DTL_TRY(d_edges_.ensure(edge_slots * 8));
-            DTL_TRY(d_counter_.ensure(16));
-            DTL_TRY(h_small_.ensure(64));
+            DTL_TRY(d_counter_.ensure(64));
+            DTL_TRY(h_small_.ensure(128));   // range counters at 0 .. 63, the call's byte total at 96
             size_t guess_total = 0;
             for (auto& r : rg) guess_total += r.guess;
             DTL_TRY(h_edges_.ensure(guess_total * 8));
-            DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 16, st));
+            DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 64, st));
             float* metric = nullptr;
             if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
             while (chunk_ev_.size() < rg.size()) {
@@ -951,59 +958,109 @@ int Receiver::stage_sync(Call& c)
                 hoff += r.guess;
             }
             lap("launch sync");
-            hoff = 0;
-            for (size_t c = 0; c < rg.size(); c++) {
+            // What the host does per range is two stages of a pipeline: (X) wait for the range's crossings, sort them,
+            // run the plateau detector; (Y) frame_detect_bb walk, arg(P) at the triggers, oscillator phases, the range's
+            // header kernel.  One thread doing both needs ~0.55 ms per 16 k triggers against 0.34 ms of sync kernel: the
+            // device would wait for the host.  With several ranges X runs on a helper thread (it touches the detector's
+            // carry state and the pinned edge buffer only; HIP calls: event wait, the rare overflow copy), Y here.
+            struct RangeOut { std::vector<int64_t> trig; int64_t produced = 0; unsigned n_edges = 0; int rc = DTL_OK; double ms = 0; bool ready = false; std::string err; };
+            std::vector<RangeOut> outs(rg.size());
+            std::mutex mu;
+            std::condition_variable cv;
+            int dev = 0;
+            DTL_HIP_CHECK(hipGetDevice(&dev));
+            auto stage_x = [&](size_t c, size_t hoff_c, RangeOut& o) -> int {
                 const Range& r = rg[c];
                 DTL_HIP_CHECK(hipEventSynchronize(chunk_ev_[c]));
-                const unsigned n_edges = h_small_.as<unsigned>()[c];
-                if (n_edges > r.max_edges) { set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
-                std::vector<unsigned long long> edges(n_edges);
-                std::memcpy(edges.data(), h_edges_.as<unsigned long long>() + hoff, size_t(std::min(n_edges, r.guess)) * 8);
-                if (n_edges > r.guess) { // more crossings than a frame stream produces: fetch the rest (all ranges are done by then or soon)
+                o.n_edges = h_small_.as<unsigned>()[c];
+                if (o.n_edges > r.max_edges) { set_last_error("sync: too many threshold crossings (noise-like input?)"); return DTL_ERR_CAPACITY; }
+                std::vector<unsigned long long> edges(o.n_edges);
+                std::memcpy(edges.data(), h_edges_.as<unsigned long long>() + hoff_c, size_t(std::min(o.n_edges, r.guess)) * 8);
+                if (o.n_edges > r.guess) { // more crossings than a frame stream produces: fetch the rest (all ranges are done by then or soon)
                     DTL_HIP_CHECK(hipMemcpy(edges.data() + r.guess, d_edges_.as<unsigned long long>() + r.off + r.guess,
-                                            size_t(n_edges - r.guess) * 8, hipMemcpyDeviceToHost));
+                                            size_t(o.n_edges - r.guess) * 8, hipMemcpyDeviceToHost));
                 }
-                hoff += r.guess;
                 const double t_e = now_ms();
                 sort_edges(edges);
                 if (A) for (auto& e : edges) e += static_cast<unsigned long long>(A) << 1; // buffer-relative -> absolute
+                o.produced = E;
+                o.trig = plateau_stream(ss.edge_carry, edges, ss.plateau_i, A + r.me, cp, final && c + 1 == rg.size(), &o.produced);
+                o.ms = now_ms() - t_e;
+                return DTL_OK;
+            };
+            std::vector<size_t> hoffs(rg.size(), 0);
+            for (size_t c = 1; c < rg.size(); c++) hoffs[c] = hoffs[c - 1] + rg[c - 1].guess;
+            // frame_detect_bb's walk over a range's triggers (what of it can be decided before later triggers and the
+            // buffer's length are known; the rest waits for stage_triggers) needs nothing from stage Y and nothing of
+            // stage Y needs it: it follows X on the helper thread, after the range's triggers have been handed over
+            auto feed_fix = [&](const RangeOut& o) {
+                if (!c_.fix) return;
+                std::vector<int64_t> rel(o.trig);
+                for (auto& t : rel) t -= ss.trig_produced;
+                c_.fix->feed(rel.data(), rel.size(), o.produced - ss.trig_produced);
+            };
+            if (cfg.use_sync_correct) {
+                ss.fds.frame_len = (L + hdr_syms) * P; // ofdm_receiver.py:77-78
+                c_.fix = std::make_unique<FixSyncRun>(ss.fds);
+            }
+            std::thread helper;
+            struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ helper };
+            if (rg.size() > 1) {
+                helper = std::thread([&]() {
+                    (void)hipSetDevice(dev);                      // a new thread starts on device 0
+                    bool failed = false;
+                    for (size_t c = 0; c < rg.size(); c++) {
+                        RangeOut& o = outs[c];
+                        if (!failed) { o.rc = stage_x(c, hoffs[c], o); failed = o.rc != DTL_OK; if (failed) o.err = last_error(); /* the error text is per thread */ }
+                        else o.rc = DTL_ERR_HIP;                  // (never reported: the caller stops at the failed range)
+                        { std::lock_guard<std::mutex> lk(mu); o.ready = true; }
+                        cv.notify_all();
+                        if (!failed) { const double t_f = now_ms(); feed_fix(o); o.ms += now_ms() - t_f; }
+                    }
+                });
+            }
+            for (size_t c = 0; c < rg.size(); c++) {
                 const bool last = c + 1 == rg.size();
-                std::vector<int64_t> trig = plateau_stream(ss.edge_carry, edges, ss.plateau_i, A + r.me, cp, final && last, &produced);
+                RangeOut& o = outs[c];
+                if (helper.joinable()) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return o.ready; });
+                } else {
+                    o.rc = stage_x(c, hoffs[c], o);
+                }
+                lap("  range: crossings sorted, plateaus found");
+                if (o.rc != DTL_OK) { if (!o.err.empty()) set_last_error(o.err); return o.rc; }
+                const unsigned n_edges = o.n_edges;
+                std::vector<int64_t>& trig = o.trig;
+                produced = o.produced;
                 const size_t first = raw_triggers.size();
                 raw_triggers.insert(raw_triggers.end(), trig.begin(), trig.end());
-                if (cfg.use_sync_correct) {
-                    // frame_detect_bb walks this range's triggers now (under the sync kernel of the next range); what
-                    // depends on later triggers or on the buffer's length waits for stage_triggers
-                    if (!c_.fix) {
-                        ss.fds.frame_len = (L + hdr_syms) * P; // ofdm_receiver.py:77-78
-                        c_.fix = std::make_unique<FixSyncRun>(ss.fds);
-                    }
-                    for (auto& t : trig) t -= ss.trig_produced;
-                    c_.fix->feed(trig.data(), trig.size(), produced - ss.trig_produced);
-                }
-                plateau_ms += now_ms() - t_e;
                 n_edges_total += n_edges;
-                // K1b for this range's triggers on the side stream (the working buffer is complete: the event just
-                // waited for sits behind its copies), then the oscillator segments of the range before it
+                // K1b for this range's triggers on the side stream (the working buffer is complete: the event waited
+                // for sits behind its copies) ...
                 if (!side_) {
                     int least = 0, greatest = 0;
                     DTL_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
                     DTL_HIP_CHECK(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, greatest));
                 }
                 DTL_TRY(submit_angles(c_, first, trig.size(), side_));
-                if (!last && c_.angle_parts.size() > 1) DTL_TRY(collect_angles(c_, c_.angle_parts.size() - 1));
-                // headers of the triggers whose oscillator segments are complete, up to the first trigger of this
-                // range (whose segment is not): queued behind the sync kernels, they keep the device busy while
-                // the host finishes the trigger list
-                if (!last) DTL_TRY(speculate_headers(c_, produced));
-                else if (c_.spec_on && !c_.hdr_launches.empty()) {
-                    // the last range as well: its angles are a few microseconds of kernel away, and with them every
-                    // oscillator segment of the call is final -- the headers of its raw triggers run while the host is
-                    // busy with frame_detect_bb and the candidate list (stage_triggers), instead of after them
+                lap("  range: submit angles");
+                if (!helper.joinable()) { feed_fix(o); lap("  range: frame_detect"); }  // (one range: everything on this thread)
+                // The oscillator segments of this range, then the headers of every trigger whose segments are complete
+                // and whose header symbols lie in front of `produced` (a later range decides what the others see):
+                // queued behind the sync kernels, they keep the device busy while the host deals with the next range
+                // -- and, for the last one, with frame_detect_bb's rest and the candidate list (stage_triggers).
+                // A call of a single range takes the unpipelined path (stage_frames launches everything).
+                if (!last || (c_.spec_on && !c_.hdr_launches.empty())) {
                     DTL_TRY(collect_angles(c_, c_.angle_parts.size()));
-                    DTL_TRY(speculate_headers(c_, final ? std::numeric_limits<int64_t>::max() : produced));
+                    lap("  range: collect angles");
+                    DTL_TRY(speculate_headers(c_, last && final ? std::numeric_limits<int64_t>::max() : produced, last));
                 }
+                lap("  range: speculate headers");
             }
+            if (helper.joinable()) helper.join();
+            for (const auto& o : outs) plateau_ms += o.ms;
+            lap("helper joined");
         } else {
             // no new samples (a final flush): close what is open
             raw_triggers = plateau_stream(ss.edge_carry, {}, ss.plateau_i, E, cp, final, &produced);
@@ -1095,7 +1152,7 @@ int Receiver::collect_angles(Call& c, size_t parts)
 // the trigger's own oscillator segment and every segment that starts inside its header symbols (`limit` = the
 // position up to which the raw trigger list is final, cut back to the first segment still waiting for its angle).  stage_frames maps the fixed triggers onto these record
 // slots and runs the kernel only for the ones that are missing (moved or inserted triggers, the last range).
-int Receiver::speculate_headers(Call& c, int64_t limit)
+int Receiver::speculate_headers(Call& c, int64_t limit, bool split_last)
 {
     StreamState& ss = *ss_;
     if (!c.spec_on || c.angle_parts_done == 0) return DTL_OK;
@@ -1167,9 +1224,9 @@ int Receiver::speculate_headers(Call& c, int64_t limit)
         c.segs_uploaded = segs_now;
     }
     uint8_t* hb = (c.flags & RX_WANT_HDR_BITS) ? d_hdr_bits.as<uint8_t>() : nullptr;
-    // a large group goes out in four launches, each with its own record copy and event: the demux walk of one part
-    // (stage_frames) then overlaps the kernels of the following ones
-    const int n_add = int(add.size()), n_parts = n_add >= 8192 ? 4 : 1;
+    // the call's last group goes out in four launches, each with its own record copy and event: the demux walk of one
+    // part (stage_frames) then overlaps the kernels of the following ones (earlier groups are long done by then)
+    const int n_add = int(add.size()), n_parts = (split_last && n_add >= 8192) ? 4 : 1;
     for (int part = 0; part < n_parts; part++) {
         const int e0 = int(int64_t(n_add) * part / n_parts), e1 = int(int64_t(n_add) * (part + 1) / n_parts);
         if (e1 <= e0) continue;
@@ -1607,7 +1664,8 @@ int Receiver::stage_blocks(Call& c)
 
     // ---- LDPC -> TB check -> compaction (the payload kernel is already running)
     tb_res.assign(size_t(n_tbs), TbResult{});
-    *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 16) = 0; // total bytes (filled by an async D2H below)
+    DTL_TRY(h_small_.ensure(128));
+    *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 96) = 0; // total bytes (filled by an async D2H below)
     DTL_TRY(d_total_.ensure(16));
     if (cfg.has_fec) {
         if (n_tbs) {
@@ -1641,7 +1699,7 @@ int Receiver::stage_blocks(Call& c)
             DTL_TRY(launch_compact(d_staging_.as<uint8_t>(), stride, d_len_.as<int32_t>(), n_tbs, d_offs_.as<uint32_t>(),
                                    d_total_.as<uint32_t>(), d_payload.as<uint8_t>(), st));
             DTL_HIP_CHECK(hipMemcpyAsync(h_tbres_.p, d_tbres_.p, size_t(n_tbs) * sizeof(TbResult), hipMemcpyDeviceToHost, st));
-            DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<uint8_t>() + 16, d_total_.p, 4, hipMemcpyDeviceToHost, st));
+            DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<uint8_t>() + 96, d_total_.p, 4, hipMemcpyDeviceToHost, st));
         }
     } else if (n_frames) {
         DTL_TRY(d_len_.ensure(size_t(n_frames) * 4));
@@ -1652,7 +1710,7 @@ int Receiver::stage_blocks(Call& c)
                                d_total_.as<uint32_t>(), d_payload.as<uint8_t>(), st));
         DTL_TRY(h_nofec_.ensure(size_t(n_frames) * 8));
         DTL_HIP_CHECK(hipMemcpyAsync(h_nofec_.p, d_nofec_info_.p, size_t(n_frames) * 8, hipMemcpyDeviceToHost, st));
-        DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<uint8_t>() + 16, d_total_.p, 4, hipMemcpyDeviceToHost, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<uint8_t>() + 96, d_total_.p, 4, hipMemcpyDeviceToHost, st));
     }
     // ---- per-frame sequential bookkeeping while the decoder is still running: lost frames (:124-138),
     // feedback decision
@@ -1689,7 +1747,7 @@ int Receiver::stage_blocks(Call& c)
     DTL_HIP_CHECK(hipStreamSynchronize(st));
     if (cfg.has_fec && n_tbs) std::memcpy(tb_res.data(), h_tbres_.p, size_t(n_tbs) * sizeof(TbResult));
     if (!cfg.has_fec && n_frames) std::memcpy(nofec_info.data(), h_nofec_.p, size_t(n_frames) * 8);
-    total_bytes = *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 16);
+    total_bytes = *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 96);
     stage_ms[6] = stage_ms[7] = 0.0;
     // (the two queries cost nothing measurable: 17.91 vs 17.89 ms per C3 step with and without them)
     if (ev_[0] && n_frames) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) stage_ms[7] = ms; }

@@ -182,7 +182,7 @@ private:
     int stage_triggers(Call& c);
     int submit_angles(Call& c, size_t first, size_t count, hipStream_t on);
     int collect_angles(Call& c, size_t parts);
-    int speculate_headers(Call& c, int64_t limit);
+    int speculate_headers(Call& c, int64_t limit, bool split_last = false);
     int stage_frames(Call& c);
     int stage_blocks(Call& c);
     int stage_records(Call& c);
@@ -204,7 +204,8 @@ private:
     hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
     std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers
     std::vector<hipEvent_t> hdr_ev_;   // one per header-kernel launch of a call
-    int64_t split_min_ = int64_t(1) << 26; // calls with at least this many new samples run the sync stage in four ranges
+    int64_t split_min_ = int64_t(1) << 26; // calls with at least this many new samples run the sync stage in several ranges
+    int sync_ranges_ = 8;
 };
 
 } // namespace dtl

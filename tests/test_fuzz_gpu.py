@@ -115,14 +115,14 @@ def _scenario(oracle, dtl, rng, plans=False):
                                                            channel=None if channel is None else channel.size)
 
 
-def _assert_production_form_equals_general_form(batch, res):
+def _assert_production_form_equals_general_form(batch, res, has_fec):
     """`res` (compared with the oracle stage by stage) asked for the equaliser's rows and therefore ran the general form of
     phase B (frame_eq_kernel<false> + demap_kernel); `batch` is what a caller gets who asks for none: the staged frame
     equaliser (no global memory inside an equaliser step) where the configuration allows it.  Same arithmetic:
     soft bits, serializer output, block records and bytes must be bit-identical."""
     assert np.array_equal(batch.tbs, res.tbs)
     np.testing.assert_array_equal(batch.payload.cpu().numpy(), res.payload.cpu().numpy())
-    for name in ("llr", "soft_syms"):
+    for name in (("llr", "soft_syms") if has_fec else ("soft_syms",)):   # (no soft bits are formed without a code)
         a, b = getattr(batch, name), getattr(res, name)
         if a is None or b is None:
             assert (a is None or a.numel() == 0) and (b is None or b.numel() == 0), name
@@ -145,14 +145,14 @@ def test_random_scenario_matches_oracle(oracle, dtl, cuda, seed):
     n_cuts = int(rng.choice([1, 3, 12, 40]))
     cuts = sorted(set(int(c) for c in rng.integers(1, max(x.size, 2), n_cuts))) if x.size > 1 else []
     batch, streamed = dtl.ofdm_receiver(pcfg).work(xt, want=("llr", "soft_syms")), _feed_all(dtl.ofdm_receiver(pcfg), xt, cuts)
-    _assert_production_form_equals_general_form(batch, res)
+    _assert_production_form_equals_general_form(batch, res, code is not None)
     if seed % 3 == 0:        # ... and the opt-in one-kernel form of phase B (soft demapper in the equaliser's epilogue)
         os.environ["DTL_RX_FUSED_PHASE_B"] = "1"
         try:
             fused = dtl.ofdm_receiver(pcfg).work(xt, want=("llr", "soft_syms"))
         finally:
             os.environ.pop("DTL_RX_FUSED_PHASE_B", None)
-        _assert_production_form_equals_general_form(fused, res)
+        _assert_production_form_equals_general_form(fused, res, code is not None)
     if pcfg.use_sync_correct and not np.array_equal(streamed[4], batch.fixed_triggers):
         # frame_detect_bb looks ahead to the end of the buffer it is given (insertion of a missing trigger, the
         # "fits into this buffer" test of a correction): as in the reference its output depends on the cuts
@@ -173,7 +173,7 @@ def test_random_scenario_with_carrier_plans(oracle, dtl, cuda, seed):
     _compare(rx, res, ref, ocfg, code is not None)
     import torch
     batch = dtl.ofdm_receiver(pcfg).work(torch.from_numpy(x).to(cuda), want=("llr", "soft_syms"))
-    _assert_production_form_equals_general_form(batch, res)
+    _assert_production_form_equals_general_form(batch, res, code is not None)
 
 
 @pytest.mark.gpu
