@@ -34,8 +34,8 @@ ofdm_adaptive_rx_hip::sptr ofdm_adaptive_rx_hip::make(const dtl_rx_cfg& cfg, con
 ofdm_adaptive_rx_hip_impl::ofdm_adaptive_rx_hip_impl(const dtl_rx_cfg& cfg, const std::string& len_tag_key)
     : gr::block("ofdm_adaptive_rx_hip", gr::io_signature::make(1, 1, sizeof(gr_complex)),
                 gr::io_signature::makev(7, 7,
-                                        { sizeof(char), sizeof(gr_complex), sizeof(char), sizeof(char),
-                                          sizeof(gr_complex) * size_t(cfg.fft_len), sizeof(gr_complex), sizeof(float) })),
+                                        std::vector<int>{ int(sizeof(char)), int(sizeof(gr_complex)), int(sizeof(char)), int(sizeof(char)),
+                                                          int(sizeof(gr_complex)) * cfg.fft_len, int(sizeof(gr_complex)), int(sizeof(float)) })),
       d_fft_len(cfg.fft_len), d_frame_length(cfg.frame_length),
       d_frame_samples((2 + (cfg.has_fec ? 2 : 1) + cfg.frame_length) * (cfg.fft_len + cfg.cp_len)),
       d_len_key(pmt::string_to_symbol(len_tag_key))
