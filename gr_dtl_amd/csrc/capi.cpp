@@ -487,6 +487,32 @@ int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers,
     return DTL_OK;
 }
 
+int dtl_sync_pretest_check(const float* d_iq, int64_t n, int32_t fft_len, float threshold, uint64_t* counts_host, void* stream)
+{
+    if (!counts_host || n < 0 || (n && !d_iq)) { dtl::set_last_error("sync_pretest_check: bad argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    counts_host[0] = counts_host[1] = counts_host[2] = 0;
+    if (n == 0) return DTL_OK;
+    if (n > int64_t(0x7fffffff)) { dtl::set_last_error("sync_pretest_check: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
+    auto* st = static_cast<hipStream_t>(stream);
+    dtl::DevBuf d_edges, d_cnt, d_chk;
+    const unsigned max_edges = unsigned(std::min<int64_t>(std::max<int64_t>(n / 2, 1024), 1 << 26));
+    int rc = d_edges.ensure(size_t(max_edges) * 8);
+    if (rc == DTL_OK) rc = d_cnt.ensure(16);
+    if (rc == DTL_OK) rc = d_chk.ensure(32);
+    if (rc != DTL_OK) return rc;
+    DTL_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, 16, st));
+    DTL_HIP_CHECK(hipMemsetAsync(d_chk.p, 0, 32, st));
+    rc = dtl::launch_sync_edges(reinterpret_cast<const dtl::cf32*>(d_iq), n, 0, fft_len, threshold, d_edges.as<unsigned long long>(),
+                                d_cnt.as<unsigned int>(), max_edges, nullptr, st, d_chk.as<unsigned long long>());
+    if (rc != DTL_OK) return rc;
+    unsigned long long c[3] = { 0, 0, 0 };
+    DTL_HIP_CHECK(hipMemcpyAsync(c, d_chk.p, sizeof(c), hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < 3; i++) counts_host[i] = uint64_t(c[i]);
+    return DTL_OK;
+}
+
 int dtl_fix_sync_chunked(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, const int64_t* buf_ends,
                          int64_t n_bufs, const int64_t* horizons, int64_t n_horizons, int64_t* out, int64_t out_cap,
                          int64_t* n_out)

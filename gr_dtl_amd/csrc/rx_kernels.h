@@ -13,9 +13,11 @@ constexpr int kSyncTileSamples = 4096;
 
 // edges / metric are produced for samples m_begin .. n-1 only (earlier samples are history of a stream
 // continued from a previous call); metric_out[m - m_begin]
+// check (tests / tools): three counters -- strips, strips the single-precision pre-test left to the exact path, outputs
+// the pre-test decided differently from the exact test (must be 0); every strip then runs both
 int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int fft_len, float threshold,
                       unsigned long long* edges, unsigned int* n_edges, unsigned int max_edges, float* metric_out,
-                      hipStream_t st);
+                      hipStream_t st, unsigned long long* check = nullptr);
 int launch_trigger_angle(const cf32* iq, int64_t n, int fft_len, const int64_t* trig, int n_trig,
                          float* angle, hipStream_t st);
 int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate* cands, int n_cand,

@@ -306,13 +306,17 @@ __device__ __forceinline__ double wave_scan(double x)
     return x;
 }
 
-template <bool WITH_METRIC, int R>
+// PRE: the per-strip interval pre-test (see the comment in front of pass C); CHECK (tools / tests only): every strip
+// also takes the exact path, and `check` counts [0] strips, [1] strips the pre-test could not decide, [2] outputs it
+// decided differently from the exact test (must stay 0).
+template <bool WITH_METRIC, int R, bool PRE = false, bool CHECK = false>
 __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R == 8 ? 6 : 2))) void sync_edges_kernel(const cf32* __restrict__ iq, int64_t n,
                                                                  int64_t m_begin, int N, float thr,
                                                                  unsigned long long* __restrict__ edges,
                                                                  unsigned int* __restrict__ n_edges,
                                                                  unsigned int max_edges,
-                                                                 float* __restrict__ metric_out)
+                                                                 float* __restrict__ metric_out,
+                                                                 unsigned long long* __restrict__ check = nullptr)
 {
     extern __shared__ double sync_smem[];
     constexpr int kSyncThreads = kSyncTile / R;
@@ -377,11 +381,15 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         const cf32* rb = raw + sync_pad<R>(base - half);
 #pragma unroll
         for (int s = 0; s < R; s++) {
+#if DTL_ABLATE == 12   // timing experiments: no pass A either (staging, barriers and scans only)
+            cr[s] = ci[s] = float(s);
+#else
             const cf32 a = ra[s], b = rb[s];
             cr[s] = a.re * b.re + a.im * b.im;
             ci[s] = a.im * b.re - a.re * b.im;
             const float e = 0.5f * (a.re * a.re + a.im * a.im);
             tr += double(cr[s]); ti += double(ci[s]); te += double(e);
+#endif
         }
     }
     double hr = 0, hi = 0, he = 0; // history strip `tid` (wave 0 only: nh <= 64)
@@ -450,23 +458,89 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     const cf32* r_new = raw + sync_pad<R>(rb_new);
     const cf32* r_half = raw + sync_pad<R>(rb_new - half);
     const cf32* r_full = raw + sync_pad<R>(rb_new - N);
-#pragma unroll
-    for (int s = 0; s < R; s++) {
-        const cf32 oa = r_half[s], ob = r_full[s];
-        const cf32 na = r_new[s];
-        const float ocr = oa.re * ob.re + oa.im * ob.im, oci = oa.im * ob.re - oa.re * ob.im;
-        const float oeh = 0.5f * (ob.re * ob.re + ob.im * ob.im);
-        const float neh = 0.5f * (na.re * na.re + na.im * na.im);
-        Wr = (Wr + double(cr[s])) - double(ocr);
-        Wi = (Wi + double(ci[s])) - double(oci);
-        We = (We + double(neh)) - double(oeh);
-        float num, den, E;
-        metric_parts(num, den, E);
-        if (WITH_METRIC) {
-            const int64_t m = m0 + s;
-            if (m >= m_begin && m < n) metric_out[m - m_begin] = E > e_floor ? num / den : __int_as_float(0x7fc00000);
+    // The exact test of the strip: the three window sums slid along it in double, rounded to float per output.
+    auto exact_strip = [&]() -> unsigned {
+        if constexpr (PRE) {
+            // rare path: what only it needs is fetched again here instead of being carried through the pre-test's loop
+            // in registers (the compiler spilled it to scratch memory from inside that loop)
+            asm volatile("" ::: "memory");
+            Wr = cp_r[km1] - cp_r[km1 - hw];
+            Wi = cp_i[km1] - cp_i[km1 - hw];
+            We = cp_e[km1] - (tid > 0 ? cp_e[tid - 1] : 0.0);
         }
-        if (above(num, den, E)) flags |= 1u << s;
+        unsigned fl = 0;
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            const cf32 oa = r_half[s], ob = r_full[s];
+            const cf32 na = r_new[s];
+            const float ocr = oa.re * ob.re + oa.im * ob.im, oci = oa.im * ob.re - oa.re * ob.im;
+            const float oeh = 0.5f * (ob.re * ob.re + ob.im * ob.im);
+            const float neh = 0.5f * (na.re * na.re + na.im * na.im);
+            float crs = cr[s], cis = ci[s];
+            if constexpr (PRE) { // (opaque copies: otherwise the sixteen conversions of pass A are kept for reuse here -- in scratch)
+                asm volatile("" : "+v"(crs));
+                asm volatile("" : "+v"(cis));
+            }
+            Wr = (Wr + double(crs)) - double(ocr);
+            Wi = (Wi + double(cis)) - double(oci);
+            We = (We + double(neh)) - double(oeh);
+            float num, den, E;
+            metric_parts(num, den, E);
+            if (WITH_METRIC) {
+                const int64_t m = m0 + s;
+                if (m >= m_begin && m < n) metric_out[m - m_begin] = E > e_floor ? num / den : __int_as_float(0x7fc00000);
+            }
+            if (above(num, den, E)) fl |= 1u << s;
+        }
+        return fl;
+    };
+    // PRE -- an interval test per STRIP in front of the per-output work.  While the windows slide over the strip's R
+    // outputs, P moves by at most V = sum of |c| over the terms that enter and leave, and |r_a conj(r_b)| <= e_a + e_b
+    // (e = |r|^2 / 2) bounds that by strip sums of the energy terms, which the coarse prefix already holds:
+    //   V <= S(k) + 2 S(k - hw) + S(k - 2 hw),   E(s) in [E0 - S(k - 2 hw), E0 + S(k)]     (S(j) = energy sum of strip j)
+    // so every output's metric lies in [ max(0, |P0| - V)^2 / Emax^2, (|P0| + V)^2 / Emin^2 ].  If that interval, widened by
+    // 1e-4 relative and a slack for the coarse prefix's own rounding (1e-9 of the tile's energy: 10^6 times its
+    // error), lies on one side of the threshold, all R flags are known: nearly every strip outside a preamble's plateau
+    // and its flanks (the metric sits near 1 / (N / 2) there, or near 1).  Every other strip -- and any strip with a
+    // window near the zero-window floor, energies whose squares leave the normal range, NaN / inf (comparisons false) --
+    // takes the exact per-output path.  dtl_sync_pretest_check / tests/test_sync_pretest_gpu.py run both on every strip
+    // of ordinary and adversarial streams: 0 disagreements.
+    bool need_exact = true;
+    [[maybe_unused]] unsigned pre_flags = 0;
+#if DTL_ABLATE == 11 || DTL_ABLATE == 12   // timing experiments: no pass C at all
+    need_exact = false;
+#else
+    if constexpr (PRE && !WITH_METRIC) {
+        const int k = nh + tid;                     // this strip; nh == 2 hw strips make an E window, hw a P window
+        const float s_new = float(cp_e[k] - cp_e[k - 1]);
+        const float s_half = float(cp_e[k - hw] - cp_e[k - hw - 1]);
+        const float s_old = float(cp_e[tid] - (tid > 0 ? cp_e[tid - 1] : 0.0));
+        const float p0r = float(Wr), p0i = float(Wi), e0 = float(We);
+        const float slack = e_tile * 1.0e-9f;
+        const float V = (s_new + 2.0f * s_half + s_old) * 1.0001f + slack;
+        const float pabs = sqrtf(p0r * p0r + p0i * p0i);
+        const float e_max = (e0 + s_new) * 1.0001f + slack, e_min = (e0 - s_old) * 0.9999f - slack;
+        const float up = pabs * 1.0001f + V, lo = fmaxf(0.0f, pabs * 0.9999f - V);
+        const bool ok = exact_ok && thr < 1.0e6f && e_min > fmaxf(fmaxf(1.0e-6f * e_tile, 2.0f * e_floor), 1.0e-15f) && e_max < 1.0e15f;
+        const bool all_below = ok && up * up < thr * 0.9999f * (e_min * e_min);
+        const bool all_above = ok && lo * lo > thr * 1.0001f * (e_max * e_max);
+        if (all_below || all_above) {
+            need_exact = false;
+            pre_flags = all_above ? ((1u << R) - 1u) : 0u;
+            flags = pre_flags;
+        }
+    }
+#endif
+    if (need_exact || CHECK) {
+        const unsigned ex = exact_strip();
+        if constexpr (CHECK) {
+            if (m0 < n) {
+                atomicAdd(&check[0], 1ull);
+                if (need_exact) atomicAdd(&check[1], 1ull);
+                else if (ex != pre_flags) atomicAdd(&check[2], (unsigned long long)__popc(ex ^ pre_flags));
+            }
+        }
+        flags = ex;
     }
     const int64_t m_last = min<int64_t>(m0 + R, n) - 1; // last valid output of the strip
     last_flag[tid] = (m_last >= m0) ? ((flags >> int(m_last - m0)) & 1u) : 0;
@@ -1603,7 +1677,8 @@ __global__ void nofec_lengths_kernel(const int32_t* __restrict__ info, int n, in
 
 // ------------------------------------------------------------------------------------------ launchers
 int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int N, float thr, unsigned long long* edges,
-                      unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st)
+                      unsigned int* n_edges, unsigned int max_edges, float* metric_out, hipStream_t st,
+                      unsigned long long* check)
 {
     if (m_begin < 0 || m_begin > n) return DTL_ERR_INVALID_ARG;
     const int R = N <= 512 ? 8 : 16;
@@ -1613,18 +1688,25 @@ int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int N, float t
     const size_t lds = size_t(N / R + threads) * 3 * sizeof(double) + size_t(n_raw + n_raw / 16 + 2) * sizeof(cf32);
     const int64_t grid = (n + kSyncTile - 1) / kSyncTile - m_begin / kSyncTile;
     if (grid <= 0) return DTL_OK;
-    using Kern = void (*)(const cf32*, int64_t, int64_t, int, float, unsigned long long*, unsigned int*, unsigned int, float*);
-    const int which = (metric_out ? 1 : 0) + (R == 16 ? 2 : 0);
-    static const Kern kerns[4] = { sync_edges_kernel<false, 8>, sync_edges_kernel<true, 8>, sync_edges_kernel<false, 16>,
-                                   sync_edges_kernel<true, 16> };
-    static size_t attr_lds[4] = { 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024 };
+    using Kern = void (*)(const cf32*, int64_t, int64_t, int, float, unsigned long long*, unsigned int*, unsigned int, float*,
+                          unsigned long long*);
+    // the single-precision pre-test serves the receive path (no metric output); DTL_SYNC_NO_PRETEST=1 keeps every strip on
+    // the exact path (A/B timing, tests); `check`: both paths on every strip, disagreements counted
+    static const bool no_pre = getenv("DTL_SYNC_NO_PRETEST") != nullptr;
+    const int variant = metric_out ? 1 : (check ? 3 : (no_pre ? 0 : 2));
+    const int which = variant + (R == 16 ? 4 : 0);
+    static const Kern kerns[8] = { sync_edges_kernel<false, 8>, sync_edges_kernel<true, 8>, sync_edges_kernel<false, 8, true>,
+                                   sync_edges_kernel<false, 8, true, true>,
+                                   sync_edges_kernel<false, 16>, sync_edges_kernel<true, 16>, sync_edges_kernel<false, 16, true>,
+                                   sync_edges_kernel<false, 16, true, true> };
+    static size_t attr_lds[8] = { 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024 };
     if (lds > attr_lds[which]) {
         DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[which]),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         attr_lds[which] = lds;
     }
     hipLaunchKernelGGL(kerns[which], dim3((unsigned)grid), dim3(threads), lds, st, iq, n, m_begin, N, thr, edges, n_edges,
-                       max_edges, metric_out);
+                       max_edges, metric_out, check);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }

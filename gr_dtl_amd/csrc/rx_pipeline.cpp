@@ -913,9 +913,9 @@ int Receiver::stage_sync(Call& c)
     unsigned n_edges_total = 0;
     {
         const int64_t mb0 = B - A;
-        // eight ranges: what the host does for a range (sort, plateau detector, frame_detect_bb walk, oscillator phases,
-        // queueing the range's header kernel) takes about as long as the range's sync kernel, so the device works through
-        // sync and header kernels back to back and only the LAST range's host share (an eighth of the call's) is exposed
+        // several ranges: what the host does for a range (sort, plateau detector, frame_detect_bb walk, oscillator phases,
+        // queueing the range's header kernel) runs while the device is busy with the next range's sync kernel and the
+        // header kernels queued so far
         const int n_sc = n >= split_min_ ? sync_ranges_ : 1;
         struct Range { int64_t mb, me; unsigned max_edges, guess; size_t off; };
         std::vector<Range> rg;

@@ -356,6 +356,10 @@ int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);
  * ofdm_adaptive_frame_detect_bb_impl::fix_sync on a sparse trigger list */
 int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, int64_t stream_len,
                  int64_t* out, int64_t out_cap, int64_t* n_out);
+/* Test aid for the sync kernel's single-precision pre-test (rx_kernels.hip, pass C): every strip of 8 (16) outputs is
+ * run through BOTH the pre-test and the exact double-precision test.  counts_host[0] = strips, [1] = strips the
+ * pre-test left to the exact path, [2] = outputs the pre-test decided differently from the exact test (must be 0). */
+int dtl_sync_pretest_check(const float* d_iq, int64_t n, int32_t fft_len, float threshold, uint64_t* counts_host, void* stream);
 /* the same over consecutive work() buffers (buffer b holds items [buf_ends[b-1], buf_ends[b]) of one trigger stream;
  * the block's state carries over), with every buffer's triggers handed to the walk piecewise: `horizons` (ascending
  * absolute positions) are the points up to which the trigger list is declared complete before the buffer's length is

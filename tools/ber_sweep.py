@@ -103,22 +103,34 @@ def deep_point(dtl, cfg, snr_db, frames_per_segment, n_cycles, seed, device, gap
         per_c[cnst]["blocks_sent"] += 1
     delivered = np.zeros(len(sent), dtype=bool)
     wrong_bits = {c: 0 for c in (1, 2, 3, 4)}
+    sent_no = np.array([t[0] for t in sent], dtype=np.int64)
     cursor = 0
+    # A delivered block names itself by an 8-bit number only, and whole segments (hundreds of blocks of one constellation)
+    # can be missing in front of it: among the sent blocks behind the cursor that carry this number (one in 256) the
+    # first one with the delivered CONTENT is the match -- a CRC-32 has vouched for the bytes.  A block that matches
+    # none within 16 number wraps counts as wrong against the first candidate.
     for t in tbs[tbs["crc_ok"] == 1]:
         nbytes = int(t["user_bits"]) // 8
         off = int(t["out_offset"])
-        want_no = int(t["tb_no"]) % 256
-        for j in range(cursor, min(cursor + 256, len(sent))):   # next sent block with this number (numbers wrap, order does not)
-            if sent[j][0] == want_no and not delivered[j]:
-                no, cnst, ui, lo, hi = sent[j]
-                if hi - lo == nbytes:
-                    got, want = payload[off:off + nbytes], users[ui][lo:hi]
-                    if not np.array_equal(got, want):
-                        wrong_bits[cnst] += int(np.unpackbits(np.bitwise_xor(got, want)).sum())
-                    delivered[j] = True
-                    per_c[cnst]["blocks_ok"] += 1
-                    cursor = j + 1
+        got = payload[off:off + nbytes]
+        cand = cursor + np.nonzero(sent_no[cursor:cursor + 4096] == int(t["tb_no"]) % 256)[0]
+        hit = None
+        for j in cand:
+            no, cnst, ui, lo, hi = sent[j]
+            if not delivered[j] and hi - lo == nbytes and np.array_equal(got, users[ui][lo:hi]):
+                hit = j
                 break
+        if hit is None:
+            for j in cand:
+                no, cnst, ui, lo, hi = sent[j]
+                if not delivered[j] and hi - lo == nbytes:
+                    wrong_bits[cnst] += int(np.unpackbits(np.bitwise_xor(got, users[ui][lo:hi])).sum())
+                    hit = j
+                    break
+        if hit is not None:
+            delivered[hit] = True
+            per_c[sent[hit][1]]["blocks_ok"] += 1
+            cursor = hit + 1
     for j, (no, cnst, ui, lo, hi) in enumerate(sent):
         if not delivered[j]:
             per_c[cnst]["bit_errors"] += (hi - lo) * 8
