@@ -41,6 +41,8 @@ int launch_header_stage(const RxTables& t, int n, const HeaderStageIo& io, Heade
                         uint8_t* hdr_bits, hipStream_t st);
 int launch_frame_eq_stage(const RxTables& t, const cf32* freq, const FrameDesc* frames, int n_frames, const cf32* taps,
                           FrameStat* stats, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, hipStream_t st);
+// *d_bad += something non-zero when a float of x[0..n) is outside {NaN, +-0, normal with |x| <= 2^62}
+int launch_range_check(const float* x, int64_t n, unsigned int* d_bad, hipStream_t st);
 // stand-alone stages (block shims, unit tests)
 void constellation_points_host(int cnst, cf32* out16);
 int launch_soft_demap(const cf32* syms, int64_t n, int cnst, double noise, int dist_mode, float* llr, hipStream_t st);

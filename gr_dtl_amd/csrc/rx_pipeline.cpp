@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 #include <condition_variable>
+#include <initializer_list>
 #include <limits>
 #include <mutex>
 #include <thread>
@@ -1312,10 +1313,30 @@ int Receiver::stage_triggers(Call& c)
 
 // ------------------------------------------------------------------ single blocks (frequency-domain vectors in)
 
+// the per-block entry points accept NaN, zeros and normal floats up to 2^62 in magnitude (see range_check_kernel)
+static int check_block_inputs(const char* what, std::initializer_list<std::pair<const cf32*, size_t>> arrays, hipStream_t st)
+{
+    DevBuf flag;
+    DTL_TRY(flag.ensure(16));
+    DTL_HIP_CHECK(hipMemsetAsync(flag.p, 0, 4, st));
+    for (const auto& a : arrays)
+        if (a.first && a.second) DTL_TRY(launch_range_check(reinterpret_cast<const float*>(a.first), int64_t(a.second) * 2, flag.as<unsigned int>(), st));
+    unsigned int bad = 0;
+    DTL_HIP_CHECK(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st));
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    if (bad) {
+        set_last_error(std::string(what) + ": input outside the supported range (every component NaN, 0 or a normal float with "
+                                           "|x| <= 2^62: denormals, infinities and larger values do not give the reference's result)");
+        return DTL_ERR_INVALID_ARG;
+    }
+    return DTL_OK;
+}
+
 int Receiver::chanest(const cf32* d_sync_syms, int n, int32_t* d_carr_off, cf32* d_taps, hipStream_t st)
 {
     if (n < 0 || (n > 0 && (!d_sync_syms || !d_carr_off || !d_taps))) { set_last_error("chanest: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (!uploaded_) DTL_TRY(upload_tables());
+    DTL_TRY(check_block_inputs("chanest", { { d_sync_syms, size_t(n) * 2 * cfg.fft_len } }, st));
     HeaderStageIo io;
     io.freq_in = d_sync_syms; io.n_rows = 2; io.row0 = 0;
     io.taps_raw_out = d_taps; io.carr_off_out = d_carr_off; io.do_header = 0;
@@ -1328,6 +1349,7 @@ int Receiver::header_decode(const cf32* d_hdr_syms, const cf32* d_taps, const in
     if (n < 0 || (n > 0 && (!d_hdr_syms || !d_taps || !d_carr_off || !recs_host))) { set_last_error("header_decode: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (n == 0) return DTL_OK;
     if (!uploaded_) DTL_TRY(upload_tables());
+    DTL_TRY(check_block_inputs("header_decode", { { d_hdr_syms, size_t(n) * cfg.header_len() * cfg.fft_len }, { d_taps, size_t(n) * cfg.fft_len } }, st));
     DevBuf recs, taps_scratch;
     DTL_TRY(recs.ensure(size_t(n) * sizeof(HeaderRec)));
     if (!d_taps_out) { DTL_TRY(taps_scratch.ensure(size_t(n) * cfg.fft_len * sizeof(cf32))); d_taps_out = taps_scratch.as<cf32>(); }
@@ -1351,6 +1373,7 @@ int Receiver::equalize_frames(const cf32* d_frames, const cf32* d_taps, const Fr
             return DTL_ERR_TAGS_MISSING;
         }
     if (!uploaded_) DTL_TRY(upload_tables());
+    DTL_TRY(check_block_inputs("equalize_frames", { { d_frames, size_t(n) * cfg.frame_length * cfg.fft_len }, { d_taps, size_t(n) * cfg.fft_len } }, st));
     DevBuf descs, stats, syms_scratch;
     DTL_TRY(descs.ensure(size_t(n) * sizeof(FrameDesc)));
     DTL_TRY(stats.ensure(size_t(n) * sizeof(FrameStat)));

@@ -15,7 +15,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 @pytest.mark.gpu
 @pytest.mark.parametrize("snr_db,gap,arith", [(18.0, 0, "gr_exact"), (24.0, 0, "gr_exact"), (30.0, 0, "gr_exact"),
                                               (22.0, 64, "gr_exact"), (28.0, 64, "gr_exact"), (21.0, 0, "fast"),
-                                              (24.0, 0, "fast")])
+                                              (24.0, 0, "fast"),
+                                              # the high end of the curve, where the deep sweep (tools/ber_sweep.py --deep,
+                                              # profiles/r03/ber_deep_*.json) measures BER 1e-3 .. 1e-5
+                                              (26.0, 0, "gr_exact"), (27.5, 0, "gr_exact"), (26.0, 0, "fast"),
+                                              (26.0, 64, "fast")])
 def test_mixed_mcs_1024_sweep_point_matches_oracle(oracle, dtl, cuda, snr_db, gap, arith):
     import torch
     import ber_sweep

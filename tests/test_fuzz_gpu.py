@@ -292,9 +292,7 @@ def test_random_equalizer_inputs_match_oracle(oracle, dtl, cuda, seed):
     pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=L)
     rx = dtl.ofdm_receiver(pcfg)
     n = int(rng.integers(1, 9))
-    # Not in the default set: denormals, |x| > 1e19 and infinities.  The equaliser's division sequences (no range scaling)
-    # and the offset search's NaN ordering are the reference's only for operands whose squares neither overflow nor
-    # underflow; outside that range both sides return garbage, but not the same garbage (DTL_FUZZ_SPECIALS explores it).
+    # Denormals, |x| > 2^62 and infinities are refused by these entry points (the next test).
     special = np.array([0.0, -0.0, np.nan], np.float64)
     if os.environ.get("DTL_FUZZ_SPECIALS"):
         special = np.array([float(v) for v in os.environ["DTL_FUZZ_SPECIALS"].split(",")])
@@ -340,6 +338,54 @@ def test_random_equalizer_inputs_match_oracle(oracle, dtl, cuda, seed):
             same_or_close(soft[j], s_ref, "soft %d" % j)
             for got, want in ((stats["snr_db"][j], snr_db), (stats["noise"][j], noise_lin)):
                 assert (got == want) or (np.isnan(got) and np.isnan(want)) or abs(got - want) <= 1e-5 * abs(want) + 1e-9, (j, got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(enumerate([np.inf, -np.inf, 1e-40, -1e-42, 3e38, -1e25, 1e19, 1e-39])), ids=lambda c: "%d" % c[0])
+def test_block_entry_points_refuse_operands_outside_the_proven_range(oracle, dtl, cuda, case):
+    """The channel estimator's and the equalisers' divisions give the oracle's bits for components that are NaN, zero or
+    normal floats up to 2^62 (DTL_FUZZ_SPECIALS=1e-30,1e-25,-1e-22 passes the test above on all seeds).  Denormals,
+    infinities and values from 1e20 up (squares overflow) used to give garbage that differed from the oracle's garbage;
+    dtl_chanest, dtl_header_decode and dtl_equalize_frames now refuse such input (DTL_ERR_INVALID_ARG), and accept the
+    same vectors once the offending component is back in range."""
+    import torch
+    from gr_dtl_amd import _lib
+    seed, special = case
+    rng = np.random.default_rng(4400 + seed)
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=64, frame_length=6)
+    rx = dtl.ofdm_receiver(pcfg)
+    n, N, L = 3, 64, 6
+
+    def vec(shape):
+        return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+    def poisoned(a):
+        b = a.copy().reshape(-1)
+        i = int(rng.integers(0, b.size))
+        b[i] = np.complex64(complex(special, b[i].imag)) if rng.integers(0, 2) else np.complex64(complex(b[i].real, special))
+        return b.reshape(a.shape)
+    sync, hdr, frames, taps = vec((n, 2, N)), vec((n, 2, N)), vec((n, L, N)), vec((n, N))
+    off = torch.zeros(n, dtype=torch.int32, device=cuda)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    calls = {
+        "chanest": lambda s, h, f, t: rx.chanest(dev(s)),
+        "header_decode": lambda s, h, f, t: rx.header_decode(dev(h), dev(t), off),
+        "equalize_frames": lambda s, h, f, t: rx.equalize_frames(dev(f), dev(t), [2] * n, [0] * n, [10] * n),
+    }
+    for name, call in calls.items():
+        call(sync, hdr, frames, taps)                                   # in range: accepted
+        bad_inputs = {"chanest": [(poisoned(sync), hdr, frames, taps)],
+                      "header_decode": [(sync, poisoned(hdr), frames, taps), (sync, hdr, frames, poisoned(taps))],
+                      "equalize_frames": [(sync, hdr, poisoned(frames), taps), (sync, hdr, frames, poisoned(taps))]}[name]
+        for args in bad_inputs:
+            with pytest.raises(_lib.DtlError) as e:
+                call(*args)
+            assert e.value.code == _lib.ERR_INVALID_ARG and "supported range" in str(e.value), (name, special)
+    # NaN and zeros stay legal operands (compared with the oracle in test_random_equalizer_inputs_match_oracle)
+    z = sync.copy()
+    z[0, 0, 3] = np.nan
+    z[1, 1, 5] = 0
+    rx.chanest(dev(z))
 
 
 @pytest.mark.gpu

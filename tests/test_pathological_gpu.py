@@ -67,3 +67,33 @@ def test_header_that_does_not_fit_is_refused(oracle, dtl, cuda):
     with pytest.raises(dtl._lib.DtlError) as e:
         rx.work(torch.zeros(5000, dtype=torch.complex64, device=cuda))
     assert e.value.code == dtl._lib.ERR_INVALID_ARG and "header" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("drop_db", [60, 90, 100])
+def test_weak_frames_behind_a_strong_burst(oracle, dtl, cuda, drop_db):
+    """The sync kernel treats a window whose energy is at or below 2^-38 (-114 dB) of its 4096-sample tile's energy as
+    "no signal" (the rounding residue of the tile's running double sums; the reference's exact FIR sums have none).  A
+    frame stream up to 100 dB below a burst that precedes it in the same tiles must still be found exactly as the oracle
+    finds it, and -- whatever the level -- identically by one batch call and by a streamed run cut anywhere: tiles are
+    aligned to the stream's sample 0, not to the call."""
+    import torch
+    from test_stream_gpu import _assert_same, _feed_all
+    pcfg, ocfg, code = make_pair(oracle, dtl, sync_threshold=0.9)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 2, 2500, None, seed=21)      # noise-free frames
+    rng = np.random.default_rng(3)
+    burst = (rng.standard_normal(3000) + 1j * rng.standard_normal(3000)).astype(np.complex64) * np.float32(40.0)
+    weak = (x * np.float32(40.0 * 10 ** (-drop_db / 20))).astype(np.complex64)
+    y = np.concatenate([burst, weak]).astype(np.complex64)
+    yt = torch.from_numpy(y).to(cuda)
+    batch = dtl.ofdm_receiver(pcfg).work(yt)
+    ref = oracle.rx_stream(ocfg, code, y, want=("frames", "trig"))
+    np.testing.assert_array_equal(batch.raw_triggers, np.nonzero(ref["trig_raw"])[0])
+    assert len(batch.frames) == ref["n_frames"] >= len(hdrs) - 2           # (the frame under the burst's tail may be lost)
+    np.testing.assert_array_equal(batch.payload.cpu().numpy(), ref["user_bytes"])
+    for cuts in ([2999], [3000, 3001, 7096], [4096, 8192], [1234, 5000, 9999, 20000]):
+        streamed = _feed_all(dtl.ofdm_receiver(pcfg), yt, [c for c in cuts if c < y.size])
+        if pcfg.use_sync_correct and not np.array_equal(streamed[4], batch.fixed_triggers):
+            np.testing.assert_array_equal(streamed[3], batch.raw_triggers)  # (frame_detect_bb looks ahead to the buffer's end)
+            continue
+        _assert_same(batch, streamed)
