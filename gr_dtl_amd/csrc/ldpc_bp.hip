@@ -317,15 +317,17 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             len0 = t.n; len1 = 0; m.k_used = t.k;
         }
         const int n_sent = ncheck + m.k_used;
+        // No branch around the loads (a lane outside the codeword reads the word at off0 -- always a valid soft bit of the
+        // stream -- and drops it): one basic block, the NV requests go out back to back, and the compiler counts them
+        // instead of draining the memory queue at every join.
 #pragma unroll
         for (int p = 0; p < NV; p++) {
             const int i = lane + p * kWave;
-            float val = kShortenedValue; // never-sent (shortened) positions, tb_decoder.cc:163-183
-            if (i < t.n && i < n_sent) {
-                if (i < len0) val = llr[size_t(off0) + i];
-                else val = (i < len0 + len1) ? llr[size_t(off1) + (i - len0)] : 0.0f; // else: never received
-            }
-            vals[p] = val;
+            const bool sent = i < t.n && i < n_sent;          // else: never-sent (shortened) positions, tb_decoder.cc:163-183
+            const bool recv = sent && i < len0 + len1;        // else: sent but never received
+            const size_t at = i < len0 ? size_t(off0) + size_t(i) : size_t(off1) + size_t(i - len0);
+            const float ld = llr[recv ? at : size_t(off0)];
+            vals[p] = recv ? ld : (sent ? 0.0f : kShortenedValue);
         }
     };
     // Codewords are claimed `chunk` at a time from a global ticket counter: the iteration count

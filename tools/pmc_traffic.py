@@ -57,7 +57,10 @@ def main():
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x1024 B x2 (gfx950 half-count "
                    "correction of MI355X_MICROARCH.md), WRITE_SIZE x1024 B; per launch averages",
            "kernels": kernels,
-           "ldpc_bp_kernel_hbm_bytes_per_launch": kernels.get("ldpc_bp", {}).get("hbm_bytes")}
+           "ldpc_bp_kernel_hbm_bytes_per_launch": kernels.get("ldpc_bp", {}).get("hbm_bytes"),
+           # phase B = frame equaliser (+ soft demapper, its own kernel or fused), summed over its launches of one step
+           "phase_b_hbm_bytes_per_step": (kernels.get("frame_eq", {}).get("hbm_bytes_per_step", 0.0) +
+                                          kernels.get("demap", {}).get("hbm_bytes_per_step", 0.0)) or None}
     if kernels:
         json.dump(doc, open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
     print(json.dumps(doc, indent=1))
