@@ -317,6 +317,12 @@ void dtl_rx_reset(dtl_rx* h) { if (h) h->rx.reset_stream(); }
 
 int64_t dtl_rx_stream_position(const dtl_rx* h) { return h ? h->rx.stream_position() : 0; }
 
+int dtl_rx_kernel_ms(dtl_rx* h, int32_t back, double* ldpc_ms, double* payload_ms)
+{
+    if (!h) { dtl::set_last_error("rx_kernel_ms: null handle"); return DTL_ERR_INVALID_ARG; }
+    return h->rx.kernel_times(back, ldpc_ms, payload_ms);
+}
+
 int dtl_sync_sc(const float* d_iq, int64_t n, int32_t fft_len, int32_t cp_len, float threshold, float* d_metric,
                 int64_t* triggers_host, float* angles_host, int64_t cap, int64_t* n_out, void* stream)
 {

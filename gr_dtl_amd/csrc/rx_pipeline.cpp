@@ -534,11 +534,24 @@ void Receiver::reset_stream()
 
 int64_t Receiver::stream_position() const { return ss_->next_abs; }
 
+int Receiver::kernel_times(int back, double* ldpc_ms, double* payload_ms)
+{
+    if (ldpc_ms) *ldpc_ms = -1.0;
+    if (payload_ms) *payload_ms = -1.0;
+    if (back < 0 || back >= kEvRing || uint64_t(back) >= n_calls_) { set_last_error("kernel_times: no such call in the ring"); return DTL_ERR_INVALID_ARG; }
+    const int slot = int((n_calls_ - 1 - uint64_t(back)) % kEvRing);
+    hipEvent_t* ev = ev_ring_[slot];
+    float ms = 0;
+    if ((ev_mask_[slot] & 1u) && payload_ms && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) *payload_ms = ms;
+    if ((ev_mask_[slot] & 2u) && ldpc_ms && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) *ldpc_ms = ms;
+    return DTL_OK;
+}
+
 // ------------------------------------------------------------------ Receiver
 
 Receiver::~Receiver()
 {
-    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& slot : ev_ring_) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     for (auto& e : chunk_ev_) if (e) (void)hipEventDestroy(e);
     if (ev_stats_) (void)hipEventDestroy(ev_stats_);
     for (auto& e : angle_ev_) if (e) (void)hipEventDestroy(e);
@@ -1518,7 +1531,7 @@ int Receiver::stage_frames(Call& c)
                                      size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
         DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.as<uint32_t>() + f0, h_llr_off_.as<uint32_t>() + f0, size_t(f1 - f0) * 4,
                                      hipMemcpyHostToDevice, st));
-        if (!payload_started && ev_[0]) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
+        if (!payload_started && ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
         DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
                                d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0, d_llr_off_.as<uint32_t>() + f0,
                                d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
@@ -1576,7 +1589,7 @@ int Receiver::stage_frames(Call& c)
     }
     DTL_TRY(flush_payload());
     if (!n_cand) { stage_ms[2] = now_ms() - t0; t0 = now_ms(); }
-    if (payload_started && ev_[1]) DTL_HIP_CHECK(hipEventRecord(ev_[1], st));
+    if (payload_started && ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[1], st)); ev_mask_[(n_calls_ - 1) % kEvRing] |= 1u; }
     if (fdesc.size()) { // per-frame SNR estimates travel back while the decoder runs
         DTL_TRY(h_stats_.ensure(fdesc.size() * sizeof(FrameStat)));
         DTL_HIP_CHECK(hipMemcpyAsync(h_stats_.p, d_stats_.p, fdesc.size() * sizeof(FrameStat), hipMemcpyDeviceToHost, st));
@@ -1706,7 +1719,7 @@ int Receiver::stage_blocks(Call& c)
                 DTL_TRY(launch_llr_gather(d_llrcopy_.as<LlrCopy>(), int(llr_copies.size()), d_llr.as<float>(), st));
             }
             DTL_TRY(launch_expand_cw(d_tbgather_.as<TbGather>(), n_tbs, d_cwdesc_.as<CwDesc>(), st));
-            if (ev_[2]) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
+            if (ev_) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
             // the decoder packs its decisions (1 bit per bit) when every code in use runs on the node-parallel kernel:
             // an eighth of the bytes out and back in; the buffer is zeroed first (the kernel ORs words in)
             bool packed = true;
@@ -1715,7 +1728,7 @@ int Receiver::stage_blocks(Call& c)
             for (auto& cr : code_ranges)
                 DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
                                                     d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st, packed));
-            if (ev_[3]) DTL_HIP_CHECK(hipEventRecord(ev_[3], st));
+            if (ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[3], st)); ev_mask_[(n_calls_ - 1) % kEvRing] |= 2u; }
             DTL_TRY(launch_tb_check(d_tbdesc_.as<TbDesc>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
                                     d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st, packed));
             DTL_TRY(d_payload.ensure(max_out_bytes + 64));
@@ -1771,10 +1784,15 @@ int Receiver::stage_blocks(Call& c)
     if (cfg.has_fec && n_tbs) std::memcpy(tb_res.data(), h_tbres_.p, size_t(n_tbs) * sizeof(TbResult));
     if (!cfg.has_fec && n_frames) std::memcpy(nofec_info.data(), h_nofec_.p, size_t(n_frames) * 8);
     total_bytes = *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 96);
+    // the kernels' device times: on request only (two event reads per pair; callers that time several steps read them
+    // afterwards through kernel_times)
     stage_ms[6] = stage_ms[7] = 0.0;
-    // (the two queries cost nothing measurable: 17.91 vs 17.89 ms per C3 step with and without them)
-    if (ev_[0] && n_frames) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) stage_ms[7] = ms; }
-    if (ev_[2] && cfg.has_fec && n_tbs) { float ms = 0; if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) stage_ms[6] = ms; }
+    if (flags & RX_WANT_KERNEL_MS) {
+        double l = -1, p2 = -1;
+        (void)kernel_times(0, &l, &p2);
+        if (l >= 0) stage_ms[6] = l;
+        if (p2 >= 0) stage_ms[7] = p2;
+    }
     n_payload_bytes = total_bytes;
     stage_ms[4] = now_ms() - t0; t0 = now_ms();
 
@@ -1898,7 +1916,12 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     if (W == 0 || (n == 0 && !final)) { reset_guard.armed = final; return DTL_OK; } // nothing consumed, nothing produced
     if (W > int64_t(0x7fffffff)) { set_last_error("process: at most 2^31-1 samples per call"); return DTL_ERR_INVALID_ARG; }
     if (!uploaded_) DTL_TRY(upload_tables());
-    if (!ev_[0]) for (auto& e : ev_) DTL_HIP_CHECK(hipEventCreate(&e));
+    {
+        const int slot = int(n_calls_++ % kEvRing);
+        if (!ev_ring_[slot][0]) for (auto& e : ev_ring_[slot]) DTL_HIP_CHECK(hipEventCreate(&e));
+        ev_ = ev_ring_[slot];
+        ev_mask_[slot] = 0;
+    }
     Call c;
     c.d_iq = d_iq; c.iq = d_iq; c.n = n; c.W = W; c.flags = flags; c.final = final; c.st = st;
     // A = absolute index of the working buffer's first sample (a multiple of the sync kernel's tile, so that

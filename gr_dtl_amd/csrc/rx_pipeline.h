@@ -103,7 +103,7 @@ struct TbInfo { // mirrors dtl_rx_tb_info
 
 enum ProcessFlags : unsigned {
     RX_WANT_EQ_HARD = 1u, RX_WANT_EQ_SOFT = 2u, RX_WANT_SOFT_SYMS = 4u, RX_WANT_HDR_BITS = 8u,
-    RX_WANT_METRIC = 16u,
+    RX_WANT_METRIC = 16u, RX_WANT_KERNEL_MS = 32u,
 };
 
 struct DevBuf {
@@ -146,6 +146,9 @@ public:
     int process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream);
     void reset_stream();
     int64_t stream_position() const; // samples consumed since the last reset
+    // device time of the phase-B kernels and of the LDPC kernel(s) of the call `back` calls ago (0 = the last one), from
+    // HIP events recorded on that call's stream; -1 where the call had none
+    int kernel_times(int back, double* ldpc_ms, double* payload_ms);
 
     // results of the last process() call
     std::vector<FrameInfo> frames;   // every trigger the demux visited, in order
@@ -191,7 +194,13 @@ private:
     RxTables tab_{};
     DevBuf tab_blob_;
     bool uploaded_ = false;
-    hipEvent_t ev_[4] = { nullptr, nullptr, nullptr, nullptr }; // HIP events around the payload / LDPC kernels
+    // HIP events around the payload / LDPC kernels: recorded on the launch stream in every call, in a ring of the last
+    // kEvRing calls; read on request (kernel_times), not inside the call -- a caller that times K steps asks afterwards
+    static constexpr int kEvRing = 32;
+    hipEvent_t ev_ring_[kEvRing][4] = {};
+    unsigned ev_mask_[kEvRing] = {};   // bit 0: payload pair recorded, bit 1: decoder pair recorded
+    uint64_t n_calls_ = 0;
+    hipEvent_t* ev_ = nullptr;         // this call's four events
     int capacity_ = 0;
     std::vector<std::unique_ptr<LdpcDecoder>> decoders_; // index 0 == nullptr ("no FEC")
     DevBuf d_edges_, d_counter_, d_trig_, d_angle_, d_cands_, d_segs_, d_recs_, d_frames_, d_stats_, d_llr_off_,

@@ -146,7 +146,7 @@ class _Result(C.Structure):
                 ("pad", C.c_int32)]
 
 
-WANT = {"eq_hard": 1, "eq_soft": 2, "soft_syms": 4, "hdr_bits": 8, "metric": 16}
+WANT = {"eq_hard": 1, "eq_soft": 2, "soft_syms": 4, "hdr_bits": 8, "metric": 16, "kernel_ms": 32}
 _FRAME_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4", C.c_double: "<f8"}[t]) for n, t in FrameInfo._fields_], align=True)
 _TB_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4"}[t]) for n, t in TbInfo._fields_], align=True)
 
@@ -261,6 +261,7 @@ class ofdm_receiver:
         L.dtl_rx_reset.restype = None
         L.dtl_rx_stream_position.argtypes = [C.c_void_p]
         L.dtl_rx_stream_position.restype = C.c_int64
+        L.dtl_rx_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.dtl_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.dtl_chanest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dtl_header_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(HeaderFields),
@@ -392,6 +393,13 @@ class ofdm_receiver:
         self._last_result = None
         if last is not None:
             last._materialise()
+
+    def kernel_ms(self, back=0):
+        """(LDPC kernel ms, phase-B kernels ms) of the call `back` calls ago, from HIP events recorded on that call's
+        stream (the handle keeps its last 32 calls); None where the call launched none."""
+        a, b = C.c_double(-1.0), C.c_double(-1.0)
+        _lib.check(_lib.lib().dtl_rx_kernel_ms(self._h, int(back), C.byref(a), C.byref(b)))
+        return (a.value if a.value >= 0 else None, b.value if b.value >= 0 else None)
 
     @property
     def stream_position(self):

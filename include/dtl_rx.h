@@ -160,7 +160,8 @@ enum dtl_rx_flags {
     DTL_RX_WANT_EQ_SOFT = 2,    /* out4 before the serializer: pre-slice symbols, L x N per frame     */
     DTL_RX_WANT_SOFT_SYMS = 4,  /* serializer output (frame_capacity per frame)                        */
     DTL_RX_WANT_HDR_BITS = 8,
-    DTL_RX_WANT_METRIC = 16     /* Schmidl-Cox metric per sample (debug)                               */
+    DTL_RX_WANT_METRIC = 16,    /* Schmidl-Cox metric per sample (debug)                               */
+    DTL_RX_WANT_KERNEL_MS = 32  /* stage_ms[6], [7] (device time of the LDPC / phase-B kernels) read inside the call */
 };
 
 /* All pointers are owned by the handle and stay valid until the next dtl_rx_process / destroy.
@@ -215,6 +216,10 @@ int dtl_rx_process_stream(dtl_rx* h, const float* d_iq, int64_t n_samples, uint3
 void dtl_rx_reset(dtl_rx* h);
 /* samples consumed since the last reset */
 int64_t dtl_rx_stream_position(const dtl_rx* h);
+/* Device time (ms) of the LDPC kernel(s) and of the phase-B kernels (frame equaliser + soft demapper) of the call `back`
+ * calls ago (0 = the last one; the handle keeps HIP events of its last 32 calls, recorded on each call's stream);
+ * -1 where that call launched none.  Reading after a series of calls keeps the event queries out of the calls. */
+int dtl_rx_kernel_ms(dtl_rx* h, int32_t back, double* ldpc_ms, double* payload_ms);
 
 /* ---------------------------------------------------------------------------------------------------
  * Batched transmitter (the frame generator).  Replaces the TX hier block of

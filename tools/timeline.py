@@ -22,7 +22,15 @@ for i, r in enumerate(rows):
         seen_ldpc = False
 if len(step_starts) < 2:
     sys.exit("no complete step found")
-a, b = step_starts[-2], step_starts[-1]
+# A "step" here runs from one call's first sync kernel to the next call's.  The last such interval of a bench run ends at
+# whatever follows the timed loop (the max-over-ranks tensors of bench.combine, the statistics pass) -- rounds 1-2 printed
+# that one and showed four small copies and > 1 ms of "idle" that belong to the bench's epilogue, not to a step.  Take the
+# interval of median length among those that are followed by another step of the same loop.
+spans = [(rows[step_starts[i + 1]][0] - rows[step_starts[i]][0], i) for i in range(len(step_starts) - 1)]
+inner = spans[:-1] if len(spans) > 2 else spans
+inner.sort()
+pick = inner[len(inner) // 2][1]
+a, b = step_starts[pick], step_starts[pick + 1]
 step = rows[a:b]
 t0 = step[0][0]
 busy_until = t0
@@ -33,4 +41,7 @@ for s, e, n in step:
     idle += gap
     print(f"{n:42s} {(s - t0) / 1e6:9.3f} {(e - s) / 1e6:8.3f} {gap / 1e6:11.3f}")
     busy_until = max(busy_until, e)
-print(f"step span {(busy_until - t0) / 1e6:.3f} ms, device idle inside it {idle / 1e6:.3f} ms, kernel time sum {sum(e - s for s, e, _ in step) / 1e6:.3f} ms")
+tail_gap = max(0, rows[b][0] - busy_until)     # from this step's last kernel to the next call's first
+print(f"step span {(busy_until - t0) / 1e6:.3f} ms, device idle inside it {idle / 1e6:.3f} ms, kernel time sum {sum(e - s for s, e, _ in step) / 1e6:.3f} ms; "
+      f"then {tail_gap / 1e6:.3f} ms until the next call's first kernel (host: block records, caller, next call's launches) "
+      f"= {(idle + tail_gap) / 1e6:.3f} ms of device idle per {(rows[b][0] - t0) / 1e6:.3f} ms period")
