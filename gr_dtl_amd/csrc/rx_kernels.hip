@@ -333,8 +333,11 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     cf32* raw = reinterpret_cast<cf32*>(cp_e + nS);
     __shared__ double wave_tot[3][kSyncThreads / 64];
     __shared__ double halo_tot[3];
-    __shared__ unsigned char last_flag[kSyncThreads];
+    __shared__ unsigned short sflags[kSyncThreads];             // per strip: threshold flags of its R outputs
+    [[maybe_unused]] __shared__ unsigned short wl[kSyncThreads]; // PRE: strips the interval pre-test left undecided
+    [[maybe_unused]] __shared__ int wl_n;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (PRE && tid == 0) wl_n = 0;                              // (the staging barrier below orders this)
 
     // Staging: every load of the thread is requested before the first one is waited for (addresses clamped into the
     // stream, values zeroed afterwards -- a bounds test around the load made the compiler run the loop as load, wait,
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     // ---- pass A: strip totals.  Sample j of the strip domain (which starts at t0 - N) is raw[half + j].
     // (the energy terms are formed again in pass C from the staged sample -- one more LDS read per output -- rather
     // than held: R more live registers here meant spills to scratch, i.e. memory round trips, at 80 VGPRs)
-    float cr[R], ci[R];
+    // (the terms are not kept: the exact per-output path forms them again from the two staged samples it reads anyway)
     double tr = 0, ti = 0, te = 0;
     {
         // strips start at multiples of R = 8 or 16 and the padding adds one element per 16: inside a strip the padded
@@ -381,14 +384,12 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         const cf32* rb = raw + sync_pad<R>(base - half);
 #pragma unroll
         for (int s = 0; s < R; s++) {
-#if DTL_ABLATE == 12   // timing experiments: no pass A either (staging, barriers and scans only)
-            cr[s] = ci[s] = float(s);
-#else
+#if DTL_ABLATE != 12   // timing experiments: 12 = no pass A either (staging, barriers and scans only)
             const cf32 a = ra[s], b = rb[s];
-            cr[s] = a.re * b.re + a.im * b.im;
-            ci[s] = a.im * b.re - a.re * b.im;
+            const float c_re = a.re * b.re + a.im * b.im;
+            const float c_im = a.im * b.re - a.re * b.im;
             const float e = 0.5f * (a.re * a.re + a.im * a.im);
-            tr += double(cr[s]); ti += double(ci[s]); te += double(e);
+            tr += double(c_re); ti += double(c_im); te += double(e);
 #endif
         }
     }
@@ -421,11 +422,7 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     }
     __syncthreads();
 
-    // ---- pass C: window sums just before the strip, then slide
-    const int km1 = nh + tid - 1;               // last strip in front of this thread's outputs (>= nh - 1 >= 3)
-    double Wr = cp_r[km1] - cp_r[km1 - hw];
-    double Wi = cp_i[km1] - cp_i[km1 - hw];
-    double We = cp_e[km1] - (tid > 0 ? cp_e[tid - 1] : 0.0);
+    // ---- pass C: per strip the window sums just before it (differences of the coarse prefix), then slide
     // threshold test: exact division-free form (see the header comment) or the plain float quotient
     const unsigned thr_bits = unsigned(__float_as_int(thr));
     const bool exact_ok = thr > 1.17549435e-38f && thr < 3.0e38f;
@@ -444,50 +441,54 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         }
         return E > e_floor && num / den >= thr;
     };
-    auto metric_parts = [&](float& num, float& den, float& E) {
+    auto metric_parts = [&](double Wr, double Wi, double We, float& num, float& den, float& E) {
         const float Pr = float(-Wr), Pi = float(-Wi);
         E = float(We);
         num = Pr * Pr + Pi * Pi;
         den = E * E;
     };
+    // window sums in front of strip `sidx`: nh == 2 hw strips make an E window, hw a P window
+    auto window_before = [&](int sidx, double& Wr, double& Wi, double& We) {
+        const int km1 = nh + sidx - 1;          // last strip in front of the strip's outputs (>= nh - 1 >= 3)
+        Wr = cp_r[km1] - cp_r[km1 - hw];
+        Wi = cp_i[km1] - cp_i[km1 - hw];
+        We = cp_e[km1] - (sidx > 0 ? cp_e[sidx - 1] : 0.0);
+    };
     const int64_t m0 = t0 + int64_t(tid) * R;
     bool prev0 = false;                         // flag of sample m0 - 1 as this tile sees it (lane 0 of the tile uses it)
-    if (tid == 0 && m0 - 1 >= 0) { float num, den, E; metric_parts(num, den, E); prev0 = above(num, den, E); }
-    unsigned flags = 0;
-    const int rb_new = N + half + tid * R;      // raw index of r[m0]
-    const cf32* r_new = raw + sync_pad<R>(rb_new);
-    const cf32* r_half = raw + sync_pad<R>(rb_new - half);
-    const cf32* r_full = raw + sync_pad<R>(rb_new - N);
-    // The exact test of the strip: the three window sums slid along it in double, rounded to float per output.
-    auto exact_strip = [&]() -> unsigned {
-        if constexpr (PRE) {
-            // rare path: what only it needs is fetched again here instead of being carried through the pre-test's loop
-            // in registers (the compiler spilled it to scratch memory from inside that loop)
-            asm volatile("" ::: "memory");
-            Wr = cp_r[km1] - cp_r[km1 - hw];
-            Wi = cp_i[km1] - cp_i[km1 - hw];
-            We = cp_e[km1] - (tid > 0 ? cp_e[tid - 1] : 0.0);
-        }
+    if (tid == 0 && m0 - 1 >= 0) {
+        double Wr, Wi, We;
+        window_before(0, Wr, Wi, We);
+        float num, den, E;
+        metric_parts(Wr, Wi, We, num, den, E);
+        prev0 = above(num, den, E);
+    }
+    // The exact test of strip `sidx` (any thread can run it: everything comes from LDS): the three window sums slid along
+    // the strip in double (+ entering term, - leaving term; the entering term c[m] = r[m] conj(r[m - N/2]) is formed from
+    // the two samples the leaving terms need anyway), rounded to float per output.
+    auto exact_strip = [&](int sidx) -> unsigned {
+        double Wr, Wi, We;
+        window_before(sidx, Wr, Wi, We);
+        const int rb_new = N + half + sidx * R; // raw index of the strip's first sample
+        const cf32* r_new = raw + sync_pad<R>(rb_new);
+        const cf32* r_half = raw + sync_pad<R>(rb_new - half);
+        const cf32* r_full = raw + sync_pad<R>(rb_new - N);
         unsigned fl = 0;
 #pragma unroll
         for (int s = 0; s < R; s++) {
             const cf32 oa = r_half[s], ob = r_full[s];
             const cf32 na = r_new[s];
+            const float ncr = na.re * oa.re + na.im * oa.im, nci = na.im * oa.re - na.re * oa.im;
             const float ocr = oa.re * ob.re + oa.im * ob.im, oci = oa.im * ob.re - oa.re * ob.im;
             const float oeh = 0.5f * (ob.re * ob.re + ob.im * ob.im);
             const float neh = 0.5f * (na.re * na.re + na.im * na.im);
-            float crs = cr[s], cis = ci[s];
-            if constexpr (PRE) { // (opaque copies: otherwise the sixteen conversions of pass A are kept for reuse here -- in scratch)
-                asm volatile("" : "+v"(crs));
-                asm volatile("" : "+v"(cis));
-            }
-            Wr = (Wr + double(crs)) - double(ocr);
-            Wi = (Wi + double(cis)) - double(oci);
+            Wr = (Wr + double(ncr)) - double(ocr);
+            Wi = (Wi + double(nci)) - double(oci);
             We = (We + double(neh)) - double(oeh);
             float num, den, E;
-            metric_parts(num, den, E);
+            metric_parts(Wr, Wi, We, num, den, E);
             if (WITH_METRIC) {
-                const int64_t m = m0 + s;
+                const int64_t m = t0 + int64_t(sidx) * R + s;
                 if (m >= m_begin && m < n) metric_out[m - m_begin] = E > e_floor ? num / den : __int_as_float(0x7fc00000);
             }
             if (above(num, den, E)) fl |= 1u << s;
@@ -501,17 +502,21 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     // so every output's metric lies in [ max(0, |P0| - V)^2 / Emax^2, (|P0| + V)^2 / Emin^2 ].  If that interval, widened by
     // 1e-4 relative and a slack for the coarse prefix's own rounding (1e-9 of the tile's energy: 10^6 times its
     // error), lies on one side of the threshold, all R flags are known: nearly every strip outside a preamble's plateau
-    // and its flanks (the metric sits near 1 / (N / 2) there, or near 1).  Every other strip -- and any strip with a
+    // and its flanks (the metric sits near 1 / (N / 2) there, or near 1).  The other strips -- and any strip with a
     // window near the zero-window floor, energies whose squares leave the normal range, NaN / inf (comparisons false) --
-    // takes the exact per-output path.  dtl_sync_pretest_check / tests/test_sync_pretest_gpu.py run both on every strip
-    // of ordinary and adversarial streams: 0 disagreements.
-    bool need_exact = true;
-    [[maybe_unused]] unsigned pre_flags = 0;
+    // go onto a work list in LDS and are then run through the exact path by the workgroup's first threads, one strip per
+    // lane: the few undecided strips of a tile (5 % in a frame stream, spread over half of its waves) cost one pass of
+    // one wave instead of one pass of every wave that holds one.  dtl_sync_pretest_check /
+    // tests/test_sync_pretest_gpu.py run both tests on every strip of ordinary and adversarial streams: 0 disagreements.
+    unsigned flags = 0;
 #if DTL_ABLATE == 11 || DTL_ABLATE == 12   // timing experiments: no pass C at all
-    need_exact = false;
+    sflags[tid] = 0;
+    __syncthreads();
 #else
     if constexpr (PRE && !WITH_METRIC) {
-        const int k = nh + tid;                     // this strip; nh == 2 hw strips make an E window, hw a P window
+        const int k = nh + tid;                     // this strip
+        double Wr, Wi, We;
+        window_before(tid, Wr, Wi, We);
         const float s_new = float(cp_e[k] - cp_e[k - 1]);
         const float s_half = float(cp_e[k - hw] - cp_e[k - hw - 1]);
         const float s_old = float(cp_e[tid] - (tid > 0 ? cp_e[tid - 1] : 0.0));
@@ -524,28 +529,36 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         const bool ok = exact_ok && thr < 1.0e6f && e_min > fmaxf(fmaxf(1.0e-6f * e_tile, 2.0f * e_floor), 1.0e-15f) && e_max < 1.0e15f;
         const bool all_below = ok && up * up < thr * 0.9999f * (e_min * e_min);
         const bool all_above = ok && lo * lo > thr * 1.0001f * (e_max * e_max);
-        if (all_below || all_above) {
-            need_exact = false;
-            pre_flags = all_above ? ((1u << R) - 1u) : 0u;
-            flags = pre_flags;
-        }
-    }
-#endif
-    if (need_exact || CHECK) {
-        const unsigned ex = exact_strip();
+        const bool decided = all_below || all_above;
+        const unsigned pre_flags = all_above ? ((1u << R) - 1u) : 0u;
         if constexpr (CHECK) {
+            const unsigned ex = exact_strip(tid);
             if (m0 < n) {
                 atomicAdd(&check[0], 1ull);
-                if (need_exact) atomicAdd(&check[1], 1ull);
+                if (!decided) atomicAdd(&check[1], 1ull);
                 else if (ex != pre_flags) atomicAdd(&check[2], (unsigned long long)__popc(ex ^ pre_flags));
             }
+            sflags[tid] = (unsigned short)ex;
+            __syncthreads();
+        } else {
+            if (decided) sflags[tid] = (unsigned short)pre_flags;
+            else wl[atomicAdd(&wl_n, 1)] = (unsigned short)tid;
+            __syncthreads();
+            const int n_wl = wl_n;
+            for (int w = tid; w < n_wl; w += kSyncThreads) {
+                const int sidx = wl[w];
+                sflags[sidx] = (unsigned short)exact_strip(sidx);
+            }
+            __syncthreads();
         }
-        flags = ex;
+    } else {
+        sflags[tid] = (unsigned short)exact_strip(tid);
+        __syncthreads();
     }
-    const int64_t m_last = min<int64_t>(m0 + R, n) - 1; // last valid output of the strip
-    last_flag[tid] = (m_last >= m0) ? ((flags >> int(m_last - m0)) & 1u) : 0;
-    __syncthreads();
-    const bool prev = tid ? (last_flag[tid - 1] != 0) : prev0;
+#endif
+    flags = sflags[tid];
+    // (a thread that goes on -- m0 < n -- has a complete strip in front of it: its last output is bit R - 1)
+    const bool prev = tid ? ((sflags[tid - 1] >> (R - 1)) & 1u) != 0 : prev0;
     if (m0 >= n) return;
     // crossings of the strip: bit s of `trans` = flag(s) != flag(s - 1); nearly every strip has none
     const int n_valid = int(min<int64_t>(R, n - m0));
