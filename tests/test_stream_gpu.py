@@ -156,3 +156,30 @@ def test_stream_outputs_per_call(oracle, dtl, cuda):
             np.testing.assert_array_equal(llr[f["llr_offset"]:f["llr_offset"] + nb].view(np.uint32),
                                           b_llr[bf["llr_offset"]:bf["llr_offset"] + nb].view(np.uint32))
     assert bi == len(b_frames)
+
+
+@pytest.mark.gpu
+def test_kernel_times_are_kept_per_call_and_read_afterwards(oracle, dtl, cuda):
+    """dtl_rx_kernel_ms: the handle records HIP events around the phase-B and LDPC kernels of every call on that call's
+    stream and keeps the last 32 calls; a caller that times several steps reads them behind its timed region."""
+    import torch
+    from gr_dtl_amd import _lib
+    pcfg, ocfg, code = make_pair(oracle, dtl)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 2, 6000, 14.0, seed=4)
+    rx = dtl.ofdm_receiver(pcfg)
+    with pytest.raises(_lib.DtlError):
+        rx.kernel_ms(0)                                  # no call yet
+    xt = torch.from_numpy(x).to(cuda)
+    for _ in range(3):
+        res = rx.work(xt, copy_outputs=False)
+    assert res.stage_ms[6] == 0.0 and res.stage_ms[7] == 0.0          # not read inside the call unless asked for
+    for back in range(3):
+        ldpc, payload = rx.kernel_ms(back)
+        assert ldpc is not None and payload is not None and 0.0 < ldpc < 100.0 and 0.0 < payload < 100.0
+    with pytest.raises(_lib.DtlError):
+        rx.kernel_ms(3)                                  # only three calls so far
+    res = rx.work(xt, want=("kernel_ms",), copy_outputs=False)
+    assert res.stage_ms[6] > 0.0 and res.stage_ms[7] > 0.0
+    empty = rx.work(torch.zeros(5000, dtype=torch.complex64, device=cuda), copy_outputs=False)   # nothing found: no kernels
+    assert rx.kernel_ms(0) == (None, None)
+
