@@ -25,11 +25,11 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
                   hipStream_t st);
 int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
                    const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
-                   const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
+                   float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
                    uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st);
 // phase B as one kernel (soft demapper in the frame equaliser's epilogue: no soft_syms hand-over buffer needed)?
 bool payload_is_fused(const RxTables& t, bool eq_rows);
-int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
+int launch_tb_check(const TbGather* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
                     int stride, TbResult* res, int32_t* len, hipStream_t st, bool packed = false);
 int launch_expand_cw(const TbGather* tbs, int n_tbs, CwDesc* out, hipStream_t st);
 int launch_llr_gather(const LlrCopy* ops, int n_ops, float* llr, hipStream_t st);

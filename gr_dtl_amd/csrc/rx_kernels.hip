@@ -993,8 +993,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
                                 const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
                                 int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
                                 cf32* __restrict__ eq_hard, cf32* __restrict__ eq_soft,
-                                cf32* __restrict__ soft_syms, const uint32_t* __restrict__ llr_off = nullptr,
-                                float* __restrict__ llr_out = nullptr, int rho0 = 0)
+                                cf32* __restrict__ soft_syms, float* __restrict__ llr_out = nullptr, int rho0 = 0)
 {
     static_assert(DEMAP < 0 || (STAGED && !FREQ_IN), "the fused demapper belongs to the staged receive-path form");
     constexpr bool FUSED = DEMAP >= 0;
@@ -1262,7 +1261,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
         const int n_syms = fd.n_syms;                 // payload == 0: frame dropped after the equaliser (:218,254)
         const int bps = fd.cnst == 4 ? 4 : fd.cnst;
         const int n_occ = occ_n;                      // data carriers per OFDM symbol (one set)
-        const uint32_t base = llr_off[blockIdx.x];
+        const uint32_t base = fd.llr_off;
         float* const llr_frame = llr_out + size_t(base);
         cf32* const soft_out_f = soft_syms ? soft_syms + size_t(blockIdx.x) * t.frame_capacity : nullptr;
         auto demap_one = [&](int q, cf32 sy) {
@@ -1318,8 +1317,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
 template <int MODE>
 __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc* __restrict__ frames,
                                                    const FrameStat* __restrict__ stats,
-                                                   const cf32* __restrict__ soft_syms,
-                                                   const uint32_t* __restrict__ llr_off, float* __restrict__ llr_out)
+                                                   const cf32* __restrict__ soft_syms, float* __restrict__ llr_out)
 {
     const int f = blockIdx.x;
     const int n_syms = frames[f].n_syms;              // payload == 0: frame dropped after the equaliser (:218,254)
@@ -1331,7 +1329,7 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     const float npwr = float(sqrt(stats[f].noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
     const float rinv = float(1.0 / double(npwr));        // the correctly rounded single reciprocal
     const cf32 s = soft_syms[size_t(f) * t.frame_capacity + q];
-    const uint32_t base = llr_off[f];
+    const uint32_t base = frames[f].llr_off;
     float* dst = llr_out + size_t(base) + size_t(q) * bps;
     float o[4];
     switch (bps) {
@@ -1422,7 +1420,7 @@ __device__ __forceinline__ uint32_t crc32_shift(uint32_t v, unsigned k, const ui
 // PACKED: `bits` holds the decoder's packed output (1 bit per bit, LSB first; block at bit offset bits_off, a multiple
 // of 8) -- the block's bytes are read as they are; otherwise one byte per bit, repacked here.
 template <bool PACKED>
-__global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__ tbs, int n_tbs,
+__global__ __launch_bounds__(64) void tb_check_kernel(const TbGather* __restrict__ tbs, int n_tbs,
                                                      const uint8_t* __restrict__ bits,
                                                      const int32_t* __restrict__ nit,
                                                      uint8_t* __restrict__ staging, int stride,
@@ -1452,7 +1450,8 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbDesc* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; j++) zmat[lane + 64 * j] = z[j];
     }
-    const TbDesc d = tbs[tb];
+    // the block's place in the decoder's output comes from its gather recipe (one table for expand_cw and this kernel)
+    const TbDesc d = { tbs[tb].bits_off, uint32_t(tbs[tb].tb_payload), tbs[tb].cw_first, uint32_t(tbs[tb].n_cw) };
     uint8_t* bytes = staging + size_t(tb) * stride;
     const int n_bytes = int(d.n_bits / 8);
     if constexpr (PACKED) {
@@ -1802,7 +1801,7 @@ int launch_frame_eq_stage(const RxTables& t, const cf32* freq, const FrameDesc* 
     const size_t lds = frame_eq_lds_bytes(t, false, false);
     if (lds > 64 * 1024) { set_last_error("frame equaliser: FFT scratch does not fit LDS"); return DTL_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL((frame_eq_kernel<false, true>), dim3(n_frames), dim3(t.fft_len), lds, st, t, freq, int64_t(0), frames,
-                       nullptr, 0, taps, stats, eq_hard, eq_soft, soft_syms, nullptr, nullptr, 0);
+                       nullptr, 0, taps, stats, eq_hard, eq_soft, soft_syms, nullptr, 0);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }
@@ -1865,7 +1864,7 @@ bool payload_is_fused(const RxTables& t, bool eq_rows)
 // (n_frames x capacity), which must exist.
 int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
                    const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
-                   const uint32_t* llr_off, float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
+                   float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
                    uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st)
 {
     if (n_frames <= 0) return DTL_OK;
@@ -1881,27 +1880,27 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
         cf32* ss = soft_syms_wanted ? soft_syms : nullptr;
         if (mode == 1)
             hipLaunchKernelGGL((frame_eq_kernel<true, false, 1>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
-                               taps, stats, eq_hard, eq_soft, ss, llr_off, llr, rho0);
+                               taps, stats, eq_hard, eq_soft, ss, llr, rho0);
         else if (mode == 2)
             hipLaunchKernelGGL((frame_eq_kernel<true, false, 2>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
-                               taps, stats, eq_hard, eq_soft, ss, llr_off, llr, rho0);
+                               taps, stats, eq_hard, eq_soft, ss, llr, rho0);
         else
             hipLaunchKernelGGL((frame_eq_kernel<true, false, 0>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
-                               taps, stats, eq_hard, eq_soft, ss, llr_off, llr, rho0);
+                               taps, stats, eq_hard, eq_soft, ss, llr, rho0);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
     }
     if (staged)
         hipLaunchKernelGGL(frame_eq_kernel<true>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
-                           stats, eq_hard, eq_soft, soft_syms, nullptr, nullptr, 0);
+                           stats, eq_hard, eq_soft, soft_syms, nullptr, 0);
     else
         hipLaunchKernelGGL(frame_eq_kernel<false>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
-                           stats, eq_hard, eq_soft, soft_syms, nullptr, nullptr, 0);
+                           stats, eq_hard, eq_soft, soft_syms, nullptr, 0);
     if (t.has_fec) {
         const dim3 grid(n_frames, (t.frame_capacity + 255) / 256);
-        if (mode == 1) hipLaunchKernelGGL(demap_kernel<1>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
-        else if (mode == 2) hipLaunchKernelGGL(demap_kernel<2>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
-        else hipLaunchKernelGGL(demap_kernel<0>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr_off, llr);
+        if (mode == 1) hipLaunchKernelGGL(demap_kernel<1>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr);
+        else if (mode == 2) hipLaunchKernelGGL(demap_kernel<2>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr);
+        else hipLaunchKernelGGL(demap_kernel<0>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr);
     } else {
         hipLaunchKernelGGL(nofec_tail_kernel, dim3(n_frames), dim3(256), 0, st, t, frames, soft_syms, nofec_bytes, nofec_info,
                            nofec_stride);
@@ -1910,7 +1909,7 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
     return DTL_OK;
 }
 
-int launch_tb_check(const TbDesc* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
+int launch_tb_check(const TbGather* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,
                     int stride, TbResult* res, int32_t* len, hipStream_t st, bool packed)
 {
     if (n_tbs <= 0) return DTL_OK;

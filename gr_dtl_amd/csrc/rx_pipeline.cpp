@@ -1466,8 +1466,6 @@ int Receiver::stage_frames(Call& c)
         DTL_TRY(d_stats_.ensure(size_t(n_cand) * sizeof(FrameStat)));
         DTL_TRY(d_frames_.ensure(size_t(n_cand) * sizeof(FrameDesc)));
         DTL_TRY(h_frames_.ensure(size_t(n_cand) * sizeof(FrameDesc)));
-        DTL_TRY(d_llr_off_.ensure(size_t(n_cand) * 4));
-        DTL_TRY(h_llr_off_.ensure(size_t(n_cand) * 4));
         if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_cand) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
         if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_cand) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
         // the equalised data symbols cross HBM (frame equaliser -> demapper) only in the two-kernel form of phase B; the
@@ -1526,14 +1524,11 @@ int Receiver::stage_frames(Call& c)
         const int f1 = int(fdesc.size());
         if (f1 <= f0) return DTL_OK;
         std::memcpy(h_frames_.as<FrameDesc>() + f0, fdesc.data() + f0, size_t(f1 - f0) * sizeof(FrameDesc));
-        std::memcpy(h_llr_off_.as<uint32_t>() + f0, llr_off.data() + f0, size_t(f1 - f0) * 4);
         DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.as<FrameDesc>() + f0, h_frames_.as<FrameDesc>() + f0,
                                      size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
-        DTL_HIP_CHECK(hipMemcpyAsync(d_llr_off_.as<uint32_t>() + f0, h_llr_off_.as<uint32_t>() + f0, size_t(f1 - f0) * 4,
-                                     hipMemcpyHostToDevice, st));
         if (!payload_started && ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
         DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
-                               d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0, d_llr_off_.as<uint32_t>() + f0,
+                               d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0,
                                d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
                                ss_out ? ss_out + size_t(f0) * capacity_ : nullptr, (flags & RX_WANT_SOFT_SYMS) != 0,
                                nofec_bytes ? nofec_bytes + size_t(f0) * nofec_stride : nullptr,
@@ -1580,6 +1575,7 @@ int Receiver::stage_frames(Call& c)
         // soft-bit stream layout: frame after frame, behind the soft bits carried for an unfinished TB
         fi.llr_offset = int64_t(llr_total);
         llr_off.push_back(uint32_t(llr_total));
+        d.llr_off = uint32_t(llr_total);
         llr_total += uint64_t(d.n_syms) * bps;
         if (llr_total + 4096 > 0xFFFFFFF0ull) { set_last_error("process: soft-bit stream exceeds 32-bit offsets; split the batch"); return DTL_ERR_CAPACITY; }
         fdesc.push_back(d);
@@ -1663,7 +1659,6 @@ int Receiver::stage_blocks(Call& c)
     // global codeword order: grouped per LDPC code, TB order inside a group
     n_tbs = int(asmb.done.size());
     std::vector<TbGather> gathers(n_tbs);
-    std::vector<TbDesc> tb_desc(n_tbs);
     std::vector<std::pair<int, std::pair<size_t, size_t>>> code_ranges; // code -> [first, count)
     uint32_t bits_total = 0;
     size_t n_cw_total = 0;
@@ -1689,7 +1684,6 @@ int Receiver::stage_blocks(Call& c)
         }
         for (int tix = 0; tix < n_tbs; tix++) {
             gathers[tix] = asmb.done[tix].g;
-            tb_desc[tix] = { gathers[tix].bits_off, uint32_t(gathers[tix].tb_payload), gathers[tix].cw_first, uint32_t(gathers[tix].n_cw) };
         }
         n_codewords = int64_t(n_cw_total);
         stride = (stride + 15) & ~15;
@@ -1713,7 +1707,6 @@ int Receiver::stage_blocks(Call& c)
             DTL_TRY(d_offs_.ensure(size_t(n_tbs) * 4));
             DTL_TRY(d_staging_.ensure(size_t(n_tbs) * stride));
             DTL_TRY(upload_vec(h_gather_, d_tbgather_, gathers, st));
-            DTL_TRY(upload_vec(h_tbdesc_, d_tbdesc_, tb_desc, st));
             if (!llr_copies.empty()) {
                 DTL_TRY(upload_vec(h_llrcopy_, d_llrcopy_, llr_copies, st));
                 DTL_TRY(launch_llr_gather(d_llrcopy_.as<LlrCopy>(), int(llr_copies.size()), d_llr.as<float>(), st));
@@ -1729,7 +1722,7 @@ int Receiver::stage_blocks(Call& c)
                 DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
                                                     d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st, packed));
             if (ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[3], st)); ev_mask_[(n_calls_ - 1) % kEvRing] |= 2u; }
-            DTL_TRY(launch_tb_check(d_tbdesc_.as<TbDesc>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
+            DTL_TRY(launch_tb_check(d_tbgather_.as<TbGather>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
                                     d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st, packed));
             DTL_TRY(d_payload.ensure(max_out_bytes + 64));
             DTL_TRY(launch_compact(d_staging_.as<uint8_t>(), stride, d_len_.as<int32_t>(), n_tbs, d_offs_.as<uint32_t>(),

@@ -203,10 +203,10 @@ private:
     hipEvent_t* ev_ = nullptr;         // this call's four events
     int capacity_ = 0;
     std::vector<std::unique_ptr<LdpcDecoder>> decoders_; // index 0 == nullptr ("no FEC")
-    DevBuf d_edges_, d_counter_, d_trig_, d_angle_, d_cands_, d_segs_, d_recs_, d_frames_, d_stats_, d_llr_off_,
-        d_cwdesc_, d_tbgather_, d_llrcopy_, d_tbdesc_, d_tbres_, d_len_, d_offs_, d_total_, d_staging_, d_nofec_info_;
-    HostBuf h_small_, h_edges_, h_trig_, h_angle_, h_cands_, h_segs_, h_recs_, h_frames_, h_llr_off_, h_gather_, h_llrcopy_,
-        h_tbdesc_, h_stats_, h_tbres_, h_nofec_;
+    DevBuf d_edges_, d_counter_, d_trig_, d_angle_, d_cands_, d_segs_, d_recs_, d_frames_, d_stats_,
+        d_cwdesc_, d_tbgather_, d_llrcopy_, d_tbres_, d_len_, d_offs_, d_total_, d_staging_, d_nofec_info_;
+    HostBuf h_small_, h_edges_, h_trig_, h_angle_, h_cands_, h_segs_, h_recs_, h_frames_, h_gather_, h_llrcopy_,
+        h_stats_, h_tbres_, h_nofec_;
     DevBuf d_work_, d_carry_, d_llr_carry_;
     std::vector<hipEvent_t> chunk_ev_; // one per candidate chunk of the phase A/B pipeline
     hipEvent_t ev_stats_ = nullptr;    // the per-frame SNR estimates have reached the host

@@ -94,7 +94,7 @@ struct FrameDesc {
     int32_t cnst;          // constellation_type_t of the payload
     int32_t carr_offset;
     int32_t n_syms;        // packet_length tag: QAM symbols carried (0 => empty frame)
-    int32_t pad;
+    uint32_t llr_off;      // where the frame's soft bits go in the call's soft-bit stream (FEC)
 };
 
 struct FrameStat {
