@@ -34,7 +34,7 @@ struct LdpcTables {
 // LDS plan of the node-parallel kernel: byte offsets of the shared index tables and of the
 // per-wave slices inside the workgroup's dynamic LDS
 struct NpShared {
-    int chk_var, var_edge, chk_deg, perm, sys_src, wave_base, wave_stride;
+    int chk_var, var_edge, chk_deg, chk_bits, wave_base, wave_stride;
 };
 
 class LdpcDecoder {
@@ -60,12 +60,13 @@ private:
     void* blob_ = nullptr;
     // node-parallel kernel (normal path)
     NpShared np_sh_{};
+    // (variables in ON-AIR numbering: variable i here is the reference's variable permute[i])
     const uint16_t* np_chk_var_ = nullptr;   // m x MAXR: variable per padded message slot (pad: n)
     const uint16_t* np_var_edge_ = nullptr;  // n x 4: message slots of a variable (pad: the slot kept at 1.0)
     const uint8_t* np_chk_deg_ = nullptr;    // m: row weights
+    const unsigned long long* np_chk_bits_ = nullptr; // NV x m: rows of H as bitmaps (syndrome check)
     bool np_rows_full_ = false;              // every row has exactly MAXR entries
     int np_maxr_ = 6;
-    const uint16_t* np_perm_ = nullptr;
     static constexpr unsigned kNpQueueRing = 256;
     unsigned int* np_queue_ = nullptr;  // ring of ticket counters of the codeword queue: one per launch
     mutable std::atomic<unsigned> np_launch_{ 0 };

@@ -21,10 +21,15 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #pragma clang fp contract(off)
+
+#ifndef DTL_ABLATE
+#define DTL_ABLATE 0 // timing experiments only (tools/ablate_ldpc.sh): 21 no syndrome check, 22 no output stage, 23 no soft-bit loads
+#endif
 
 namespace dtl {
 
@@ -154,9 +159,19 @@ __global__ __launch_bounds__(kWave) void ldpc_bp_kernel(LdpcTables t, const floa
 // instructions than the edge-parallel form for the same IEEE operations in the same order.
 // A 1024-thread workgroup keeps 16 codewords (one per wave) in one CU's 160 KB LDS next to a
 // single copy of the code's index tables; waves never synchronise with each other.
+// Variables are numbered in ON-AIR order (variable i here == the reference's variable permute[i]): soft bits are
+// used where they land (lane l of load p holds variable l + 64 p), hard decisions are NV 64-bit ballot words, the
+// syndrome is parity(row bitmap AND decisions), and the data bits are that bitmap shifted down by `rank` bits -- no
+// scatter through the permutation, no per-variable decision bytes, no lookups of the systematic positions.
+// The kernel is bound by instruction issue (measured on gfx950: ~one wave instruction of ANY kind per SIMD per 4
+// cycles -- instructions/codeword x 4 cycles x codewords/SIMD reproduces the kernel time both for clean codewords
+// and for the receive chain's mix, profiles/r03/ldpc_zero_iteration.txt), so every instruction removed counts the
+// same, scalar or vector, and memory waits matter only in that they must not serialise.
 // ------------------------------------------------------------------------------------------
 constexpr int kNpWaves = 16;
 constexpr int kNpChunk = 16;  // codewords per queue ticket (large batches)
+constexpr int kNpQueues = 8;       // ticket counters per launch ...
+constexpr int kNpQueueStride = 16; // ... this many 32-bit words apart (one 64-byte line each)
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                                                                      const uint16_t* __restrict__ chk_var_g,
                                                                      const uint16_t* __restrict__ var_edge_g,
                                                                      const uint8_t* __restrict__ chk_deg_g,
-                                                                     const uint16_t* __restrict__ perm_g,
+                                                                     const unsigned long long* __restrict__ chk_bits_g,
                                                                      const float* __restrict__ llr,
                                                                      const CwDesc* __restrict__ desc, int ncw,
                                                                      int max_it, float sigma,
@@ -271,63 +286,87 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     uint16_t* chk_var = reinterpret_cast<uint16_t*>(np_smem + sh.chk_var);    // m * MAXR
     uint16_t* var_edge = reinterpret_cast<uint16_t*>(np_smem + sh.var_edge);  // n * 4
     uint8_t* chk_deg = np_smem + sh.chk_deg;                                  // m
-    uint16_t* perm = reinterpret_cast<uint16_t*>(np_smem + sh.perm);
-    uint16_t* sys_src = reinterpret_cast<uint16_t*>(np_smem + sh.sys_src);
+    unsigned long long* chk_bits = reinterpret_cast<unsigned long long*>(np_smem + sh.chk_bits); // m x (NV | 1) row bitmaps
     const int n_slots = t.m * MAXR;
     for (int i = threadIdx.x; i < n_slots; i += blockDim.x) chk_var[i] = chk_var_g[i];
     for (int i = threadIdx.x; i < t.n * 4; i += blockDim.x) var_edge[i] = var_edge_g[i];
     for (int i = threadIdx.x; i < t.m; i += blockDim.x) chk_deg[i] = chk_deg_g[i];
-    for (int i = threadIdx.x; i < t.n; i += blockDim.x) perm[i] = perm_g[i];
-    for (int i = threadIdx.x; i < t.k; i += blockDim.x) sys_src[i] = t.sys_src[i];
+    for (int i = threadIdx.x; i < t.m * (NV | 1); i += blockDim.x) chk_bits[i] = chk_bits_g[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char* mine = np_smem + sh.wave_base + size_t(wave) * sh.wave_stride;
     double* msg = reinterpret_cast<double*>(mine);   // n_slots messages + [n_slots] == 1.0 (+ one spare)
     double* rx = msg + n_slots + 2;                  // n channel LRs + rx[n] == 0 (dummy variable)
-    uint8_t* est = reinterpret_cast<uint8_t*>(rx + t.n + 1); // n hard decisions + est[n] == 0
-    float* ybuf = reinterpret_cast<float*>(msg);
+    // hard decisions on their way out, 1 bit each: NV + 1 64-bit words (last: 0) over the first channel LRs, which are
+    // dead once a codeword's iterations have ended and are written again only behind the next pass's `emit`
+    uint32_t* xw = reinterpret_cast<uint32_t*>(rx);
     const int kOneSlot = n_slots;
     const int ncheck = t.n - t.k;
     const float s2 = sigma * sigma;
 
-    auto syndrome_ok = [&]() -> bool {
+    // Hard decisions are NV uniform 64-bit words (X[p] bit l = decision of variable l + 64 p: one v_cmp each); row c of H
+    // is NV 64-bit masks in LDS (check-major with an odd stride in words: one address per lane, constant offsets, and the
+    // 64-bit reads of a pass fall on distinct banks), and the syndrome bit of a check is the parity of the AND of the
+    // two -- no per-variable lookups.
+    auto syndrome_ok = [&](const unsigned long long (&X)[NV]) -> bool {
+#if DTL_ABLATE == 21
+        return __ballot(X[0] == 0xdeadbeefull) == 0ull;
+#endif
         unsigned bad = 0;
-        for (int c = lane; c < t.m; c += kWave) {
-            unsigned s = 0;
+        for (int c0 = 0; c0 < t.m; c0 += kWave) {
+            const int c = min(c0 + lane, t.m - 1);        // (a lane past the last check repeats it)
+            unsigned long long fold = 0;
 #pragma unroll
-            for (int j = 0; j < MAXR; j++) s ^= est[chk_var[c * MAXR + j]];
-            bad |= s;
+            for (int p = 0; p < NV; p++) fold ^= chk_bits[c * (NV | 1) + p] & X[p];
+            bad |= unsigned(__popc(unsigned(fold) ^ unsigned(fold >> 32))) & 1u;
         }
         return __ballot(bad != 0) == 0ull;
     };
-
-    // soft bits of one codeword in on-air order, lane l holds positions l, l+64, ... (coalesced);
-    // the NEXT codeword's soft bits are fetched before the current one is decoded so that the HBM
-    // latency hides behind the belief propagation (or behind the previous codeword's syndrome).
-    struct Meta { uint32_t out_off; int k_used; };
-    auto fetch = [&](int cw, float (&vals)[NV], Meta& m) {
-        uint32_t off0, off1;
-        int len0, len1;
+    // The memory pipeline of a wave: while codeword i is decoded, the soft bits of i + 1 are in flight and the
+    // descriptor of i + 2 is being read -- through the SCALAR cache, as five whole dwords, so that waiting for it never
+    // drains the vector-memory queue (a 16-bit field read makes the compiler use a vector load plus
+    // s_waitcnt vmcnt(0), which waits for the soft bits just requested and for the previous codeword's stores: one
+    // full memory latency per codeword, 3/4 of the time of a codeword that needs no iteration).
+    struct Meta { uint32_t off0, off1, out_off; int len0, len1, k_used, n_sent, n_recv; };
+    auto load_meta = [&](int cw, Meta& m) {
         if (desc) {
-            const CwDesc d = desc[cw];
-            off0 = d.llr_off0; off1 = d.llr_off1; m.out_off = d.out_off; len0 = d.len0; len1 = d.len1; m.k_used = d.k_used;
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(desc + cw);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+            m.off0 = w0; m.off1 = w1; m.out_off = w2; m.len0 = int(w3 & 0xFFFFu); m.len1 = int(w3 >> 16); m.k_used = int(w4 & 0xFFFFu);
         } else {
-            off0 = uint32_t(cw) * uint32_t(t.n); off1 = 0; m.out_off = uint32_t(cw) * uint32_t(t.k);
-            len0 = t.n; len1 = 0; m.k_used = t.k;
+            m.off0 = uint32_t(cw) * uint32_t(t.n); m.off1 = 0; m.out_off = uint32_t(cw) * uint32_t(t.k);
+            m.len0 = t.n; m.len1 = 0; m.k_used = t.k;
         }
-        const int n_sent = ncheck + m.k_used;
-        // No branch around the loads (a lane outside the codeword reads the word at off0 -- always a valid soft bit of the
-        // stream -- and drops it): one basic block, the NV requests go out back to back, and the compiler counts them
-        // instead of draining the memory queue at every join.
+        m.n_sent = min(ncheck + m.k_used, t.n);        // beyond: never sent (shortened), tb_decoder.cc:163-183
+        m.n_recv = min(m.n_sent, m.len0 + m.len1);     // beyond: sent but never received
+    };
+    // Soft bits of one codeword in on-air order, lane l holds positions l, l+64, ... (coalesced).  The loads are
+    // unconditional -- a lane outside the received part reads the codeword's last received soft bit (or the word at
+    // off0: always a valid soft bit of the stream) -- and their values are put right (`settle`) only where the
+    // codeword becomes the current one: no branch and no use of a loaded value near the loads, so the requests go out
+    // back to back and nothing waits for them here.
+    auto fetch = [&](const Meta& m, float (&raw)[NV]) {
+        const unsigned last = unsigned(max(m.n_recv, 1) - 1);
+        // position i of the codeword is soft bit off0 + i of the stream, or off1 + (i - len0) behind a frame boundary:
+        // one 32-bit sum either way (offsets are 32-bit stream positions; the wrap-around of `hop` cancels)
+        const unsigned len0 = unsigned(m.len0), hop = m.off1 - m.off0 - len0;
+#pragma unroll
+        for (int p = 0; p < NV; p++) {
+            const unsigned i = min(unsigned(lane + p * kWave), last);
+            const uint32_t at = m.off0 + i + (i < len0 ? 0u : hop);
+#if DTL_ABLATE == 23
+            raw[p] = __uint_as_float(at | 0x80000000u);
+#else
+            raw[p] = llr[size_t(at)];
+#endif
+        }
+    };
+    auto settle = [&](const Meta& m, const float (&raw)[NV], float (&vals)[NV]) {
 #pragma unroll
         for (int p = 0; p < NV; p++) {
             const int i = lane + p * kWave;
-            const bool sent = i < t.n && i < n_sent;          // else: never-sent (shortened) positions, tb_decoder.cc:163-183
-            const bool recv = sent && i < len0 + len1;        // else: sent but never received
-            const size_t at = i < len0 ? size_t(off0) + size_t(i) : size_t(off1) + size_t(i - len0);
-            const float ld = llr[recv ? at : size_t(off0)];
-            vals[p] = recv ? ld : (sent ? 0.0f : kShortenedValue);
+            vals[p] = i < m.n_recv ? raw[p] : (i < m.n_sent ? 0.0f : kShortenedValue);
         }
     };
     // Codewords are claimed `chunk` at a time from a global ticket counter: the iteration count
@@ -342,19 +381,41 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     const int n_big = (ncw - tail_cw) / chunk;                  // codewords [0, n_big * chunk) in big chunks
     const int tail_first = n_big * chunk;
     const int n_tail = (ncw - tail_first + kTailChunk - 1) / kTailChunk;
+    // Same-address device-scope atomics complete one every ~11.5 ns on this part (measured: a launch of 2^20
+    // clean codewords took tickets x 11.5 ns whatever else the kernel did), so (a) the chunks are dealt round-robin to
+    // kNpQueues counters in different cache lines -- a wave draws from its workgroup's home counter and moves on to the
+    // next counter when one has run out (each counter is probed at most once past its end by a wave) -- and (b) a
+    // wave asks for its NEXT ticket when it starts a chunk, not when it has finished it: the reply is back long before
+    // it is needed (it returns in order with the soft-bit loads the wave waits for anyway).
+    const int n_chunks = n_big + n_tail;
     int chunk_next = 0, chunk_end = 0;
+    int home = int(blockIdx.x) % kNpQueues, queues_left = kNpQueues;
+    unsigned pending = 0;                                 // lane 0: the reply to the outstanding request
+    auto request = [&]() {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(queue + home * kNpQueueStride, 1u);
+        pending = v;
+    };
+    request();
     auto advance = [&]() -> int {
         if (chunk_next == chunk_end) {
-            unsigned v = 0;
-            if (lane == 0) v = atomicAdd(queue, 1u);
-            v = __builtin_amdgcn_readfirstlane(v);
-            if (v >= unsigned(n_big + n_tail)) return ncw;
-            if (int(v) < n_big) {
-                chunk_next = int(v) * chunk;
-                chunk_end = chunk_next + chunk;
-            } else {
-                chunk_next = tail_first + (int(v) - n_big) * kTailChunk;
-                chunk_end = min(chunk_next + kTailChunk, ncw);
+            if (queues_left == 0) return ncw;
+            for (;;) {
+                const int g = int(__builtin_amdgcn_readfirstlane(pending)) * kNpQueues + home;   // chunk number
+                if (g < n_chunks) {
+                    if (g < n_big) {
+                        chunk_next = g * chunk;
+                        chunk_end = chunk_next + chunk;
+                    } else {
+                        chunk_next = tail_first + (g - n_big) * kTailChunk;
+                        chunk_end = min(chunk_next + kTailChunk, ncw);
+                    }
+                    request();
+                    break;
+                }
+                if (--queues_left == 0) return ncw;
+                home = (home + 1) % kNpQueues;
+                request();
             }
         }
         return chunk_next++;
@@ -457,43 +518,92 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             }
         }
     };
-    float cur[NV], nxt[NV];
-    Meta mcur{ 0, 0 }, mnxt{ 0, 0 };
-    int cw = advance();
-    if (cw < ncw) fetch(cw, cur, mcur);
-    // The first codeword's soft bits are waited for HERE.  Without this the compiler has to assume, inside the loop,
-    // that loads into `cur` may still be in flight (true only on the first pass) and -- loads being counted in one
-    // in-order queue -- drains the queue at the first LDS read of every codeword, i.e. waits for the prefetch of the
-    // NEXT codeword it has just issued instead of decoding under it.
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    while (cw < ncw) {
-        const int cw_next = advance();
-        if (cw_next < ncw) fetch(cw_next, nxt, mnxt);
-        const uint32_t out_off = mcur.out_off;
-        const int k_used = mcur.k_used;
-        // scatter to y[permute[i]] = -llr[i] (ldpc_dec.cc:64-66)
-#pragma unroll
-        for (int p = 0; p < NV; p++) {
-            const int i = lane + p * kWave;
-            if (i < t.n) {
-                const float y = -1 * cur[p];
-                const int v = perm[i];
-                ybuf[v] = y;
-                est[v] = (y < 0) ? 1 : 0;
+    // The stores of a codeword go out at the TOP of the next pass, just before the next soft bits are requested:
+    // loads and stores share one in-order counter (s_waitcnt vmcnt), so the wait for the next codeword's soft bits at
+    // the bottom of a pass also waits for every store issued before it -- stores issued at the bottom would be waited
+    // for at once (a full write latency per codeword), stores issued at the top have had a whole pass to complete.
+    // The decisions stay in the wave's LDS bitmap in between.
+    int prev_cw = -1, prev_nit = 0, prev_k_used = 0;
+    uint32_t prev_out_off = 0;
+    auto emit = [&]() {
+        const uint32_t out_off = prev_out_off;
+        const int k_used = prev_k_used;
+        if (packed) {
+            // 1 bit per bit, LSB first (what fec_pack / the CRC check want) at bit position out_off of the zeroed output
+            const bool bytewise = ((out_off | unsigned(k_used)) & 7u) == 0;  // the usual case: whole bytes, plain stores
+            if (bytewise) {
+                if (8 * lane < k_used) {                                     // k_used <= 512: one byte per lane
+                    const int q = t.rank + 8 * lane;
+                    const unsigned long long two = (unsigned long long)(xw[q >> 5]) | ((unsigned long long)(xw[(q >> 5) + 1]) << 32);
+                    out_bits[size_t(out_off >> 3) + lane] = uint8_t(two >> (q & 31));
+                }
+            } else if (64 * lane < k_used) {
+                // codewords of a block are not byte aligned in general: 64 bits per lane, OR-ed into the output words
+                unsigned long long* words = reinterpret_cast<unsigned long long*>(out_bits);
+                const int q = t.rank + 64 * lane, d = q >> 5, s = q & 31;
+                const unsigned long long a = (unsigned long long)(xw[d]) | ((unsigned long long)(xw[d + 1]) << 32);
+                const unsigned long long b = (unsigned long long)(xw[d + 1]) | ((unsigned long long)(xw[d + 2]) << 32);
+                unsigned long long w = (unsigned long long)(uint32_t(a >> s)) | ((unsigned long long)(uint32_t(b >> s)) << 32);
+                const int left = k_used - 64 * lane;
+                if (left < 64) w &= (1ull << left) - 1ull;
+                if (w) {
+                    const unsigned long long pos = (unsigned long long)(out_off) + (unsigned long long)(64 * lane);
+                    const unsigned sh = unsigned(pos & 63ull);
+                    atomicOr(&words[pos >> 6], w << sh);
+                    if (sh && (w >> (64 - sh))) atomicOr(&words[(pos >> 6) + 1], w >> (64 - sh));
+                }
+            }
+        } else {
+            for (int i = lane; i < k_used; i += kWave) {
+                const int q = t.rank + i;
+                out_bits[size_t(out_off) + i] = uint8_t((xw[q >> 5] >> (q & 31)) & 1u);
             }
         }
-        if (lane == 0) est[t.n] = 0;
-        wave_sync();
+        if (lane == 0) out_nit[prev_cw] = prev_nit;
+        wave_sync(); // the bitmap is rewritten by the next codeword
+    };
+    float cur[NV], nxt[NV];
+    Meta m0{}, m1{}, m2{};
+    int cw = advance();
+    int cw1 = cw < ncw ? advance() : ncw;
+    if (cw < ncw) { load_meta(cw, m0); fetch(m0, nxt); }
+    if (cw1 < ncw) load_meta(cw1, m1);
+    settle(m0, nxt, cur);
+    while (cw < ncw) {
+        const int cw2 = cw1 < ncw ? advance() : ncw;     // (a new ticket: an atomic, waited for before anything else goes out)
+#if DTL_ABLATE == 22
+        if (prev_cw >= 0 && lane == 0) out_nit[prev_cw] = prev_nit;
+#else
+        if (prev_cw >= 0) emit();
+#endif
+        if (cw1 < ncw) fetch(m1, nxt);
+        if (cw2 < ncw) load_meta(cw2, m2);
+        const uint32_t out_off = m0.out_off;
+        const int k_used = m0.k_used;
+        // Variables are numbered in ON-AIR order here (variable i of the tables == the reference's variable permute[i],
+        // ldpc_dec.cc:64-66: y[permute[i]] = -llr[i]): lane l holds the soft bits of variables l, l + 64, ... as they
+        // arrived, and nothing has to be scattered.  awgn_bp::compute_init_estimate: 1 where y = -llr < 0.
+        unsigned long long X[NV];
+#pragma unroll
+        for (int p = 0; p < NV; p++) {
+            const float y = -1 * cur[p];
+            X[p] = __ballot(y < 0);                       // (positions >= n hold the shortened value: 0)
+        }
         int nit = 0;
-        if (!syndrome_ok()) {
+        if (!syndrome_ok(X)) {
             bool wild = false;                            // a channel exponent outside the tame range (or NaN)
-            for (int v = lane; v < t.n; v += kWave) {
-                float arg = (-1 * 2 * ybuf[v]) / s2;
+#pragma unroll
+            for (int p = 0; p < NV; p++) {
+                const int v = lane + p * kWave;
+                const float y = -1 * cur[p];
+                float arg = (-1 * 2 * y) / s2;
                 // written as comparisons: NaN (no ordering) takes the last branch -- the compiler may turn an fmin/fmax clamp
                 // into a median instruction whose NaN result differs
                 if (FAST) arg = arg > kFastLlrMax ? kFastLlrMax : (arg >= -kFastLlrMax ? arg : -kFastLlrMax);
-                wild |= !(fabsf(arg) <= kTameArgMax);
-                rx[v] = dm_exp64(double(arg));
+                if (v < t.n) {
+                    wild |= !(fabsf(arg) <= kTameArgMax);
+                    rx[v] = dm_exp64(double(arg));
+                }
             }
             if (lane == 0) rx[t.n] = 0.0;
             wave_sync();
@@ -518,7 +628,8 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                     // lane's reads of a pass precede its writes (one wave, program order), and the slot is set back to
                     // 1.0 behind the writes of each pass (one uniform store instead of a compare + select per entry)
                     unsigned char* msg_b = reinterpret_cast<unsigned char*>(msg);
-                    for (int v = lane; v < t.n; v += kWave) {
+                    unsigned dec = 0;                     // bit p: decision of variable lane + 64 p
+                    for (int p = 0, v = lane; v < t.n; p++, v += kWave) {
                         const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
                         int ee[MAXC];
                         double rr[MAXC];
@@ -537,7 +648,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                             for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
 #pragma unroll
                             for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = pre[i] * suf[i];
-                            est[v] = (pre[MAXC] > 1) ? 1 : 0;
+                            dec |= (pre[MAXC] > 1 ? 1u : 0u) << p;
                         } else {
                             double sum = rx[v];
 #pragma unroll
@@ -548,12 +659,14 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                             }
 #pragma unroll
                             for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = div_exact<TAME>(sum, rr[i]);
-                            est[v] = (sum > 1) ? 1 : 0;
+                            dec |= (sum > 1 ? 1u : 0u) << p;
                         }
                         msg[kOneSlot] = 1.0;
                     }
                     wave_sync();
-                    if (syndrome_ok()) break;
+#pragma unroll
+                    for (int p = 0; p < NV; p++) X[p] = __ballot(((dec >> p) & 1u) != 0);
+                    if (syndrome_ok(X)) break;
                 }
             };
             // exact arithmetic: the cheaper division form when every channel exponent of this codeword is tame (see
@@ -561,33 +674,23 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             if (FAST || __ballot(wild) != 0ull) iterate(std::false_type{});
             else iterate(std::true_type{});
         }
-        if (packed) {
-            // 1 bit per bit, LSB first (what fec_pack / the CRC check want): 64 decisions per ballot, OR-ed into the
-            // zeroed output words at bit position out_off (codewords of a block are not byte aligned in general)
-            unsigned long long* words = reinterpret_cast<unsigned long long*>(out_bits);
-            const bool bytewise = ((out_off | unsigned(k_used)) & 7u) == 0;  // the usual case: whole bytes, plain stores
-            for (int i0 = 0; i0 < k_used; i0 += kWave) {
-                const int i = i0 + lane;
-                const unsigned long long w = __ballot(i < k_used && est[sys_src[i < k_used ? i : 0]] != 0);
-                if (bytewise) {
-                    if (lane < 8 && i0 + 8 * lane < k_used) out_bits[(size_t(out_off) + size_t(i0)) / 8 + lane] = uint8_t(w >> (8 * lane));
-                } else if (lane == 0 && w) {
-                    const unsigned long long pos = (unsigned long long)(out_off) + (unsigned long long)(i0);
-                    const unsigned sh = unsigned(pos & 63ull);
-                    atomicOr(&words[pos >> 6], w << sh);
-                    if (sh && (w >> (64 - sh))) atomicOr(&words[(pos >> 6) + 1], w >> (64 - sh));
-                }
-            }
-        } else {
-            for (int i = lane; i < k_used; i += kWave) out_bits[size_t(out_off) + i] = est[sys_src[i]];
-        }
-        if (lane == 0) out_nit[cw] = nit;
-        wave_sync(); // the wave's LDS slice is reused by its next codeword
+        // cldpc::get_systematic_bits: data bit i is variable permute[rank + i], i.e. on-air position rank + i -- the
+        // output is the decision bitmap shifted down by `rank` bits.  The bitmap goes through the wave's LDS slice as
+        // NV + 1 64-bit words (the last one zero); every output lane reads the dwords its bits straddle.
+        {
+            unsigned long long word = 0;
 #pragma unroll
-        for (int p = 0; p < NV; p++) cur[p] = nxt[p];
-        mcur = mnxt;
-        cw = cw_next;
+            for (int p = 0; p < NV; p++) word = lane == p ? X[p] : word;
+            if (lane <= NV) reinterpret_cast<unsigned long long*>(xw)[lane] = word;
+        }
+        wave_sync();
+        // (the stores themselves: `emit`, at the top of the next pass)
+        prev_cw = cw; prev_nit = nit; prev_out_off = out_off; prev_k_used = k_used;
+        settle(m1, nxt, cur);
+        m0 = m1; m1 = m2;
+        cw = cw1; cw1 = cw2;
     }
+    if (prev_cw >= 0) emit();
 }
 
 } // namespace
@@ -626,9 +729,7 @@ int LdpcDecoder::upload()
     size_t o_ev = put(edge_var.data(), edge_var.size() * 2);
     size_t o_ip = put(inv_perm.data(), inv_perm.size() * 2);
     size_t o_ss = put(sys_src.data(), sys_src.size() * 2);
-    std::vector<uint16_t> perm16 = to16(code.permute);
-    size_t o_pm = put(perm16.data(), perm16.size() * 2);
-    const std::vector<unsigned int> zeros(kNpQueueRing, 0u);
+    const std::vector<unsigned int> zeros(size_t(kNpQueueRing) * kNpQueues * kNpQueueStride, 0u);
     size_t o_q = put(zeros.data(), zeros.size() * sizeof(unsigned int));
     // fixed-stride tables of the node-parallel kernel (see the kernel's comment)
     const bool small_code = code.max_row_deg <= 6 && code.max_col_deg <= 3 && code.n <= 320; // kernel <6,3,5>
@@ -643,7 +744,7 @@ int LdpcDecoder::upload()
         chk_deg[c] = uint8_t(std::min(deg, 255));
         if (deg != maxr) rows_full = false;
         for (int j = 0; j < deg && j < maxr; j++) {
-            chk_var[size_t(c) * maxr + j] = uint16_t(code.edge_var[code.row_ptr[c] + j]);
+            chk_var[size_t(c) * maxr + j] = inv_perm[code.edge_var[code.row_ptr[c] + j]];   // on-air numbering
             slot_of_edge[code.row_ptr[c] + j] = j * code.m + c;   // entry-major message layout
         }
     }
@@ -651,10 +752,20 @@ int LdpcDecoder::upload()
     std::vector<uint16_t> var_edge(size_t(code.n) * 4, uint16_t(n_slots * 8)); // pad -> the slot kept at 1.0
     for (int v = 0; v < code.n; v++)
         for (int i = code.col_ptr[v]; i < code.col_ptr[v + 1] && i - code.col_ptr[v] < 4; i++)
-            var_edge[size_t(v) * 4 + (i - code.col_ptr[v])] = uint16_t(slot_of_edge[code.col_edge[i]] * 8);
+            var_edge[size_t(inv_perm[v]) * 4 + (i - code.col_ptr[v])] = uint16_t(slot_of_edge[code.col_edge[i]] * 8);
     size_t o_cv = put(chk_var.data(), chk_var.size() * 2);
     size_t o_ve = put(var_edge.data(), var_edge.size() * 2);
     size_t o_cd = put(chk_deg.data(), chk_deg.size());
+    // row bitmaps of H in on-air numbering: word p of check c (at [c * stride + p], stride = NV | 1) has bit l set iff
+    // variable l + 64 p is in row c
+    const int nv_words = small_code ? 5 : 8, nv_stride = nv_words | 1;
+    std::vector<unsigned long long> chk_bits(size_t(code.m) * nv_stride, 0ull);
+    for (int c = 0; c < code.m; c++)
+        for (int e = code.row_ptr[c]; e < code.row_ptr[c + 1]; e++) {
+            const int v = inv_perm[code.edge_var[e]];
+            if (v < 64 * nv_words) chk_bits[size_t(c) * nv_stride + (v >> 6)] ^= 1ull << (v & 63);
+        }
+    size_t o_cb = put(chk_bits.data(), chk_bits.size() * 8);
     if (blob_) { (void)hipFree(blob_); blob_ = nullptr; }
     DTL_HIP_CHECK(hipMalloc(&blob_, host.size()));
     DTL_HIP_CHECK(hipMemcpy(blob_, host.data(), host.size(), hipMemcpyHostToDevice));
@@ -668,10 +779,10 @@ int LdpcDecoder::upload()
     t_.edge_var = reinterpret_cast<const uint16_t*>(b + o_ev);
     t_.inv_perm = reinterpret_cast<const uint16_t*>(b + o_ip);
     t_.sys_src = reinterpret_cast<const uint16_t*>(b + o_ss);
-    np_perm_ = reinterpret_cast<const uint16_t*>(b + o_pm);
     np_chk_var_ = reinterpret_cast<const uint16_t*>(b + o_cv);
     np_var_edge_ = reinterpret_cast<const uint16_t*>(b + o_ve);
     np_chk_deg_ = b + o_cd;
+    np_chk_bits_ = reinterpret_cast<const unsigned long long*>(b + o_cb);
     np_rows_full_ = rows_full;
     np_maxr_ = maxr;
     np_queue_ = reinterpret_cast<unsigned int*>(b + o_q);
@@ -682,13 +793,13 @@ int LdpcDecoder::upload()
         np_sh_.chk_var = int(off); off = al(off + size_t(n_slots) * 2);
         np_sh_.var_edge = int(off); off = al(off + size_t(code.n) * 4 * 2);
         np_sh_.chk_deg = int(off); off = al(off + size_t(code.m));
-        np_sh_.perm = int(off); off = al(off + size_t(code.n) * 2);
-        np_sh_.sys_src = int(off); off = al(off + size_t(code.k) * 2);
+        np_sh_.chk_bits = int(off); off = al(off + size_t(code.m) * nv_stride * 8);
         np_sh_.wave_base = int(off);
-        // per-wave slice: padded message slots + 2, channel LRs + 1, hard decisions + 1
-        np_sh_.wave_stride = int(al(size_t(n_slots + 2) * 8 + size_t(code.n + 1) * 8 + size_t(code.n + 1)));
+        // per-wave slice: padded message slots + 2, channel LRs + 1 (their first 9 words double as the decision bitmap
+        // on its way out: n >= 9 is checked below)
+        np_sh_.wave_stride = int(al(size_t(n_slots + 2) * 8 + size_t(code.n + 1) * 8));
         np_lds_ = off + size_t(kNpWaves) * np_sh_.wave_stride;
-        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && (n_slots + 2) * 8 < 65535 &&
+        np_ok_ = code.max_row_deg <= 8 && code.max_col_deg <= 4 && code.n <= 512 && code.n >= 9 && (n_slots + 2) * 8 < 65535 &&
                  np_lds_ <= 160 * 1024;
         if (np_ok_) {
             for (auto kern : { reinterpret_cast<const void*>(ldpc_bp_np_kernel<6, 3, 5, true, false>),
@@ -727,12 +838,14 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
         // Large batches take 16 codewords per ticket (keeps the same-address atomics off the critical
         // path); small ones shrink the ticket so that all 4096 waves get work and the tail stays short (at 25 k
         // codewords, C2, two per ticket measured 0.36 ms against 0.44 ms for one or four).
-        const int chunk = int(std::max<size_t>(1, std::min<size_t>(kNpChunk, ncw / (size_t(grid) * kNpWaves * 3))));
+        // (DTL_LDPC_CHUNK: tuning experiments, tools/ablate_ldpc.sh)
+        static const int chunk_cap = [] { const char* e = std::getenv("DTL_LDPC_CHUNK"); return e ? std::max(1, atoi(e)) : kNpChunk; }();
+        const int chunk = int(std::max<size_t>(1, std::min<size_t>(size_t(chunk_cap), ncw / (size_t(grid) * kNpWaves * 3))));
         // every launch takes its own ticket counter from a ring: two decodes of one decoder on different streams
         // (legal: decode() is const and takes the caller's stream) never share one
-        unsigned int* queue = np_queue_ + (np_launch_.fetch_add(1, std::memory_order_relaxed) % kNpQueueRing);
-        DTL_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned int), stream));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_chk_var_, np_var_edge_, np_chk_deg_, np_perm_,
+        unsigned int* queue = np_queue_ + size_t(np_launch_.fetch_add(1, std::memory_order_relaxed) % kNpQueueRing) * kNpQueues * kNpQueueStride;
+        DTL_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned int) * kNpQueues * kNpQueueStride, stream));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_chk_var_, np_var_edge_, np_chk_deg_, np_chk_bits_,
                            d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk, packed ? 1 : 0);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
