@@ -99,3 +99,60 @@ def test_gather_descriptor_shortened(oracle, dtl, cuda):
         np.testing.assert_array_equal(got[o:o + k_used[i]], ref_bits[i, :k_used[i]])
         o += int(k_used[i])
     assert ref_nit.max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", ["gr_exact", "fast"])
+@pytest.mark.parametrize("alist", [ALIST_300, ALIST_100_23, ALIST_100_27])
+def test_gather_descriptors_partial_reception(oracle, dtl, cuda, alist, arith):
+    """Every shape a codeword's descriptor can take (lib/dtl/tb_decoder.cc:143-195): whole, cut in two anywhere with a
+    gap in the stream, received only in part (the rest of the sent positions count as 0), not received at all,
+    shortened down to one data bit; clean codewords (no iteration: the decoder's short path) mixed with noisy ones.
+    The decoder reads soft bits where they lie in the stream, so the stream is NaN outside the received pieces."""
+    import torch
+    from gr_dtl_amd._lib import CwDesc
+    code = oracle.Ldpc(alist)
+    dec = dtl.ldpc_dec(alist, arith=arith)
+    rng = np.random.default_rng(code.n * 7 + code.k + len(arith))
+    ncw, ncheck = 1500, code.n - code.k
+    descs, full = (CwDesc * ncw)(), np.full((ncw, code.n), -15.0, np.float32)
+    pieces, pos, out_off, k_useds = [], 5, 0, []
+    for i in range(ncw):
+        k_used = int(rng.integers(1, code.k + 1)) if i % 3 else code.k
+        d = np.zeros(code.k, np.uint8)
+        d[:k_used] = rng.integers(0, 2, k_used)
+        want = ncheck + k_used
+        cw = code.encode(d)[:want]
+        noise = (0.0, 1.5, 2.8)[i % 3 if i % 7 else 2]
+        llr = ((2.0 * cw - 1) * 4 + rng.normal(0, 1, want) * noise).astype(np.float32)
+        how = i % 5
+        recv = want if how < 3 else (int(rng.integers(1, want)) if how == 3 else (0 if i % 10 == 4 else int(rng.integers(1, want))))
+        full[i, :recv] = llr[:recv]
+        full[i, recv:want] = 0.0
+        len0 = recv if how == 0 else int(rng.integers(0, recv + 1))
+        if recv > 0 and len0 == 0 and i % 2:
+            len0 = 1
+        gap = int(rng.integers(0, 40))
+        off0 = pos if len0 > 0 or i % 4 else 0          # (a codeword whose start was never received: offset 0, length 0)
+        descs[i] = CwDesc(off0, pos + len0 + gap, out_off, len0, recv - len0, k_used, 0)
+        pieces.append((pos, llr[:len0]))
+        pieces.append((pos + len0 + gap, llr[len0:recv]))
+        pos += recv + gap + int(rng.integers(0, 4))
+        out_off += k_used
+        k_useds.append(k_used)
+    buf = np.full(pos + 8, np.nan, np.float32)
+    buf[0] = 3.0                                         # offset 0 is read (and dropped) for pieces of length 0
+    for p, seg in pieces:
+        buf[p:p + seg.size] = seg
+    ref_bits, ref_nit = code.decode_batch(full, n_threads=8, **({"arith": oracle.FAST} if arith == "fast" else {}))
+    d_desc = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(cuda)
+    out_bits = torch.full((out_off,), 7, dtype=torch.uint8, device=cuda)
+    out_nit = torch.full((ncw,), -1, dtype=torch.int32, device=cuda)
+    dec.decode_gather(torch.from_numpy(buf).to(cuda), d_desc, out_bits, out_nit)
+    got = out_bits.cpu().numpy()
+    np.testing.assert_array_equal(out_nit.cpu().numpy(), ref_nit)
+    o = 0
+    for i in range(ncw):
+        np.testing.assert_array_equal(got[o:o + k_useds[i]], ref_bits[i, :k_useds[i]], err_msg=f"codeword {i}")
+        o += k_useds[i]
+    assert (ref_nit == 0).mean() > 0.1 and (ref_nit > 0).mean() > 0.2
