@@ -16,6 +16,8 @@ namespace dtl {
 // Both functions are written branch-free: the main path runs for every input and the special cases are
 // selected at the end (v_cndmask), because a wave that demaps 64 symbols would otherwise pay ~150 scalar
 // branches per symbol.  Results are those of the straightforward early-return forms (the CPU oracle's).
+// NONPOS: the caller guarantees x <= 0 and not NaN (then the overflow and NaN selects do nothing and are left out)
+template <bool NONPOS = false>
 __device__ __forceinline__ float dm_exp(float x)
 {
     const float kf = rintf(x * 1.44269504f);
@@ -33,6 +35,7 @@ __device__ __forceinline__ float dm_exp(float x)
     // p * 2^k with a single rounding (v_ldexp_f32); bit-identical to the CPU oracle's two-step
     // (p * 2^(k/2)) * 2^(k - k/2), whose first product is exact (tools/math_check.hip: all 2^32 inputs)
     float res = ldexpf(p, k);
+    if constexpr (NONPOS) return (x < -103.97208f) ? 0.0f : res;
     res = (x > 88.72283905f) ? __int_as_float(0x7f800000) : res;
     res = (x < -103.97208f) ? 0.0f : res;
     return (x != x) ? x : res;
@@ -123,10 +126,12 @@ __device__ __forceinline__ float dm_div_inrange(float a, float b)
 // which rounds correctly once the reciprocal is within an ulp -- here it is exact to half an ulp.  Anything that
 // is not an ordinary finite quotient takes the plain division.  Results in the subnormal range may differ in the
 // last bit, which the demapper cannot see (exp of both is exactly 1).  tools/math_check.hip compares with -a / b.
+// ORDINARY: the caller guarantees a * r < 3e38 and b < 3e38 (the guard does nothing and is left out)
+template <bool ORDINARY = false>
 __device__ __forceinline__ float dm_neg_div_by(float a, float b, float r)
 {
     float q = a * r;
-    if (!(q < 3.0e38f) || !(b < 3.0e38f)) return -a / b;
+    if constexpr (!ORDINARY) { if (!(q < 3.0e38f) || !(b < 3.0e38f)) return -a / b; }
     float e = __builtin_fmaf(-b, q, a);
     q = __builtin_fmaf(e, r, q);
     e = __builtin_fmaf(-b, q, a);
@@ -148,9 +153,11 @@ __device__ __forceinline__ double dm_div_by_count(double a, double n, double r)
     return __builtin_fma(e, r, q);
 }
 
+// NORMAL: the caller guarantees 2^-126 <= x0 < inf (no rescaling of tiny arguments, no special results)
+template <bool NORMAL = false>
 __device__ __forceinline__ float dm_log(float x0)
 {
-    const bool tiny = x0 < 1.17549435e-38f;
+    const bool tiny = !NORMAL && x0 < 1.17549435e-38f;
     const float x = tiny ? x0 * 33554432.0f : x0;
     int e = tiny ? -25 : 0;
     unsigned ix = unsigned(__float_as_int(x));
@@ -167,6 +174,7 @@ __device__ __forceinline__ float dm_log(float x0)
     const float hfsq = 0.5f * f * f;
     const float ef = float(e);
     float res = __builtin_fmaf(ef, 6.9313812256e-01f, f - (hfsq - __builtin_fmaf(s, hfsq + R, ef * 9.0580006145e-06f)));
+    if constexpr (NORMAL) return res;
     res = (x0 == __int_as_float(0x7f800000)) ? x0 : res;
     res = (x0 == 0.0f) ? __int_as_float(0xff800000) : res;
     res = (x0 < 0.0f) ? __int_as_float(0x7fc00000) : res;

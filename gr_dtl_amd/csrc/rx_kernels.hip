@@ -831,7 +831,39 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
 // distances): 16-QAM in the separable form -- exp(-(dx^2 + dy^2)/npwr) factors, the other axis' factor cancels in
 // P(bit = 1) / P(bit = 0), so a bit needs the 4 levels of its own axis: 8 exp + 8 log instead of 16 + 8 (oracle:
 // calc_soft_dec_qam16_fast; NOT the reference's bits).  Other constellations: as mode 0.
-template <int BPS, int MODE>
+// o[j] = log(p1[j]) - log(p0[j]); ORD: without the logarithm's special cases when every sum of the wave is a normal number
+// (the sums are sums of exponentials <= 1: finite; a bit value whose nearest point is ~87 noise scales away underflows)
+template <int BPS, bool ORD>
+__device__ __forceinline__ void demap_log_ratios(const float (&p1)[BPS], const float (&p0)[BPS], float* __restrict__ o)
+{
+    if constexpr (ORD) {
+        float least = p1[0];
+#pragma unroll
+        for (int j = 0; j < BPS; j++) least = fminf(least, fminf(p1[j], p0[j]));
+        if (__all(least >= 1.17549435e-38f)) {
+#pragma unroll
+            for (int j = 0; j < BPS; j++) o[j] = dm_log<true>(p1[j]) - dm_log<true>(p0[j]);
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BPS; j++) o[j] = dm_log(p1[j]) - dm_log(p0[j]);
+}
+
+// the per-lane half of soft_demap_symbol's ORD precondition (the caller takes the ORD form when it holds for every
+// lane of the wave): |re|, |im| <= 1e4 and 1e-20 <= npwr <= 1e20 -- a distance (squared or not) is then below 3e8, its
+// quotient by npwr below 3e28, and neither is NaN
+__device__ __forceinline__ bool demap_operands_ordinary(cf32 s, float npwr)
+{
+    return fabsf(s.re) <= 1.0e4f && fabsf(s.im) <= 1.0e4f && npwr >= 1.0e-20f && npwr <= 1.0e20f;
+}
+
+// ORD ("ordinary operands", decided per wave by the caller: demap_operands_ordinary): the symbol is finite and of
+// moderate size and the noise scale is an ordinary positive number, so every exponent is a finite number <= 0 and the
+// quotient guard, the exponential's overflow / NaN selects -- and, when all the sums of a wave turn out to be normal
+// numbers (checked here), the logarithm's rescaling and special results -- would select nothing: the same operations
+// in the same order without them, a quarter fewer instructions.
+template <int BPS, int MODE, bool ORD = false>
 __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict__ pts, float npwr, float rinv,
                                                   float* __restrict__ o)
 {
@@ -843,14 +875,13 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
         for (int q = 0; q < 4; q++) {
             const float dr = s.re - pts[q << 1].re;                        // points 0, 2, 4, 6: the four real levels
             const float di = s.im - pts[(q & 1) | ((q >> 1) << 3)].im;     // points 0, 1, 8, 9: the four imaginary levels
-            er[q] = dm_exp(dm_neg_div_by(dr * dr, npwr, rinv));
-            ei[q] = dm_exp(dm_neg_div_by(di * di, npwr, rinv));
+            er[q] = dm_exp<ORD>(dm_neg_div_by<ORD>(dr * dr, npwr, rinv));
+            ei[q] = dm_exp<ORD>(dm_neg_div_by<ORD>(di * di, npwr, rinv));
         }
         // index bit 1 / 2 = LSB / MSB of the real level, bit 0 / 3 = LSB / MSB of the imaginary level; LSB first
-        o[0] = dm_log(ei[1] + ei[3]) - dm_log(ei[0] + ei[2]);
-        o[1] = dm_log(er[1] + er[3]) - dm_log(er[0] + er[2]);
-        o[2] = dm_log(er[2] + er[3]) - dm_log(er[0] + er[1]);
-        o[3] = dm_log(ei[2] + ei[3]) - dm_log(ei[0] + ei[1]);
+        const float a1[4] = { ei[1] + ei[3], er[1] + er[3], er[2] + er[3], ei[2] + ei[3] };
+        const float a0[4] = { ei[0] + ei[2], er[0] + er[2], er[0] + er[1], ei[0] + ei[1] };
+        demap_log_ratios<4, ORD>(a1, a0, o);
         return;
     }
     float p0[BPS], p1[BPS];
@@ -882,15 +913,14 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
         }
         // compile-time switch: a runtime select would evaluate the correctly rounded sqrtf for every point
         const float dist = PLAIN_DIST ? sqrtf(sq) : sq;
-        const float d = dm_exp(dm_neg_div_by(dist, npwr, rinv)); // -dist / npwr exactly; fixed-sequence expf (dtl_math.h)
+        const float d = dm_exp<ORD>(dm_neg_div_by<ORD>(dist, npwr, rinv)); // -dist / npwr exactly; fixed-sequence expf (dtl_math.h)
 #pragma unroll
         for (int j = 0; j < BPS; j++) {
             if ((m >> j) & 1) p1[j] += d;
             else p0[j] += d;
         }
     }
-#pragma unroll
-    for (int j = 0; j < BPS; j++) o[j] = dm_log(p1[j]) - dm_log(p0[j]);
+    demap_log_ratios<BPS, ORD>(p1, p0, o);
 }
 
 // dist_mode argument (0 / 1, + DTL_DEMAP_FAST) -> MODE of soft_demap_symbol; the fast form exists for squared distances
@@ -1332,19 +1362,26 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     const uint32_t base = frames[f].llr_off;
     float* dst = llr_out + size_t(base) + size_t(q) * bps;
     float o[4];
+    const bool ord = __all(demap_operands_ordinary(s, npwr));   // wave-uniform: see soft_demap_symbol
     switch (bps) {
     case 1: soft_demap_symbol<1, MODE>(s, pts, npwr, rinv, o); dst[0] = o[0]; break;
     case 2:
-        soft_demap_symbol<2, MODE>(s, pts, npwr, rinv, o);
+        if (ord) soft_demap_symbol<2, MODE, true>(s, pts, npwr, rinv, o);
+        else soft_demap_symbol<2, MODE>(s, pts, npwr, rinv, o);
         // a symbol's soft bits leave in ONE store when the frame's position in the stream allows it (a frame starts
         // wherever the previous ones ended): four dword stores at a 16-byte stride make the memory pipeline handle
         // 64 four-byte pieces each
         if ((base & 1u) == 0) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
         else { dst[0] = o[0]; dst[1] = o[1]; }
         break;
-    case 3: soft_demap_symbol<3, MODE>(s, pts, npwr, rinv, o); dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; break;
+    case 3:
+        if (ord) soft_demap_symbol<3, MODE, true>(s, pts, npwr, rinv, o);
+        else soft_demap_symbol<3, MODE>(s, pts, npwr, rinv, o);
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        break;
     default:
-        soft_demap_symbol<4, MODE>(s, pts, npwr, rinv, o);
+        if (ord) soft_demap_symbol<4, MODE, true>(s, pts, npwr, rinv, o);
+        else soft_demap_symbol<4, MODE>(s, pts, npwr, rinv, o);
         if ((base & 3u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
         break;

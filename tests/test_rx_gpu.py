@@ -135,6 +135,27 @@ def test_fec_chain_matches_oracle_64(oracle, dtl, cuda, cnst, esn0, nbytes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("cnst,esn0", [(4, 34.0), (4, 44.0), (4, 52.0), (4, 70.0), (4, 90.0), (2, 48.0), (3, 55.0), (1, 60.0)])
+def test_soft_bits_from_ordinary_to_vanishing_noise(oracle, dtl, cuda, cnst, esn0, mode):
+    """The chain's demapper drops the special cases of its exp / log / quotient sequences when a wave's operands are
+    ordinary (rx_kernels.hip soft_demap_symbol<.., ORD>): here the noise estimate shrinks until first the sums of the
+    unlikely bit values underflow (the logarithms go back to their full form: -inf and NaN soft bits appear) and then
+    the noise scale itself leaves the ordinary range (everything does) -- every soft bit equal to the oracle's."""
+    pcfg, ocfg, code = make_pair(oracle, dtl, llr_dist_mode=mode)
+    user, hdrs, x = make_stream(oracle, ocfg, code, cnst, 4000, esn0, seed=700 + cnst + int(esn0))
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x)
+    assert ref["n_frames"] >= 0.99 * len(hdrs)
+    before = list(STATS["llr"])
+    _compare(rx, res, ref, ocfg, True)                    # (soft bits of frames whose noise estimates are the same number)
+    exact, total = STATS["llr"][0] - before[0], STATS["llr"][1] - before[1]
+    assert total >= 0.5 * res.llr.numel() and exact == total, (exact, total)
+    llr = res.llr.cpu().numpy()
+    if esn0 >= 52.0 and cnst > 1:
+        assert not np.isfinite(llr).all()                 # the underflow regime was reached
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cnst,esn0", [(2, 14.0), (3, 22.0), (4, 25.0)])
 def test_plain_distance_llr_mode(oracle, dtl, cuda, cnst, esn0):
     """llr_dist_mode=1: the demapper's metric is the plain distance (sqrtf) instead of its square (the other
