@@ -18,6 +18,7 @@
 #include "dtl_math.h"
 
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -1749,6 +1750,8 @@ int launch_sync_edges(const cf32* iq, int64_t n, int64_t m_begin, int N, float t
                                    sync_edges_kernel<false, 16>, sync_edges_kernel<true, 16>, sync_edges_kernel<false, 16, true>,
                                    sync_edges_kernel<false, 16, true, true> };
     static size_t attr_lds[8] = { 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024 };
+    static std::mutex attr_mu;                            // (receivers may run in several host threads)
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
     if (lds > attr_lds[which]) {
         DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[which]),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -1800,6 +1803,8 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
     if (n_cand <= 0) return DTL_OK;
     const size_t lds = header_lds_bytes(t);
     static size_t attr_lds = 64 * 1024;
+    static std::mutex attr_mu;
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
     if (lds > attr_lds) {
         DTL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(header_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -1955,6 +1960,8 @@ int launch_tb_check(const TbGather* tbs, int n_tbs, const uint8_t* bits, const i
     // zero-append maps of the CRC-32 register for 2^j bytes, j = 0..15 (built once per process and device)
     static uint32_t* d_zmat = nullptr;
     static int zmat_dev = -1;
+    static std::mutex zmat_mu;
+    std::lock_guard<std::mutex> zmat_lock(zmat_mu);
     int dev = 0;
     DTL_HIP_CHECK(hipGetDevice(&dev));
     if (!d_zmat || zmat_dev != dev) {
@@ -2109,6 +2116,8 @@ int launch_fft_batch(const cf32* in, cf32* out, int64_t n_vec, int N, int forwar
     // twiddle / bit-reversal tables per transform length, built once per process and device
     struct Tab { int N, dev; cf32* tw; uint16_t* br; };
     static std::vector<Tab> tabs;
+    static std::mutex tabs_mu;
+    std::lock_guard<std::mutex> tabs_lock(tabs_mu);
     int dev = 0;
     DTL_HIP_CHECK(hipGetDevice(&dev));
     const Tab* t = nullptr;
@@ -2138,6 +2147,8 @@ static int crc_zero_maps(uint32_t** out, int levels)
 {
     static uint32_t* d_z = nullptr;
     static int z_dev = -1;
+    static std::mutex z_mu;
+    std::lock_guard<std::mutex> z_lock(z_mu);
     int dev = 0;
     DTL_HIP_CHECK(hipGetDevice(&dev));
     if (!d_z || z_dev != dev) {

@@ -524,12 +524,17 @@ Receiver::Receiver() : ss_(std::make_unique<StreamState>())
     // tests lower the threshold so that small streams take the pipelined (four ranges, early header launches) path
     if (const char* e = getenv("DTL_RX_SPLIT_MIN")) split_min_ = std::max<int64_t>(1, atoll(e));
     if (const char* e = getenv("DTL_RX_SYNC_RANGES")) sync_ranges_ = std::min(16, std::max(1, atoi(e)));
+    if (const char* e = getenv("DTL_RX_FLUSH_FRAMES")) flush_frames_ = std::max(64, atoi(e));   // (tuning experiments)
+    if (const char* e = getenv("DTL_RX_FLUSH_FIRST")) flush_first_ = std::max(64, atoi(e));
 }
 
 void Receiver::reset_stream()
 {
+    const double t_a = now_ms();
     if (side_) (void)hipStreamSynchronize(side_); // a failed call may leave trigger-angle work in flight
+    const double t_b = now_ms();
     ss_ = std::make_unique<StreamState>();
+    if (getenv("DTL_DEBUG")) fprintf(stderr, "  [reset_stream: side stream %.3f ms, state %.3f ms]\n", t_b - t_a, now_ms() - t_b);
 }
 
 int64_t Receiver::stream_position() const { return ss_->next_abs; }
@@ -1550,7 +1555,7 @@ int Receiver::stage_frames(Call& c)
         // phase B does not wait for the end of the walk (nor for a launch boundary: one early candidate with a late
         // record slot -- a trigger frame_detect_bb moved -- consumes all of them at once): the frames found so far go out
         // after the first 2048 and then every 8192
-        if (int(fdesc.size()) - f0 >= (f0 == 0 ? 2048 : 8192)) DTL_TRY(flush_payload());
+        if (int(fdesc.size()) - f0 >= (f0 == 0 ? flush_first_ : flush_frames_)) DTL_TRY(flush_payload());
         const int64_t trig = cand_abs[ci];
         n_walked = ci + 1;
         if (trig < ss.demux_pos) continue; // consumed by a previous frame

@@ -213,6 +213,7 @@ private:
     hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
     std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers
     std::vector<hipEvent_t> hdr_ev_;   // one per header-kernel launch of a call
+    int flush_first_ = 2048, flush_frames_ = 8192; // phase B is handed over after this many frames of the demux walk (first / later hand-overs)
     int64_t split_min_ = int64_t(1) << 26; // calls with at least this many new samples run the sync stage in several ranges
     int sync_ranges_ = 4;                  // measured: 4 -> 17.7 ms per C3 step, 6 -> 17.8, 8 -> 18.1 (per-range launch and copy overhead)
 };
