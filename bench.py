@@ -188,7 +188,7 @@ def decoder_under_load(dtl, device, arith, ncw=1 << 20, esn0_db=-1.0, reps=3):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     its = float(nit.float().mean().item())
-    # instruction bound: wave instructions of one iteration of the kernel's loop (ISA listing, profiles/r02/
+    # instruction bound: wave instructions of one iteration of the kernel's loop (ISA listing, profiles/r03/
     # ldpc_isa_counts.txt) x 4 cycles, 1024 SIMDs at 2.4 GHz
     instr = LDPC_WAVE_INSTR_PER_ITERATION[arith]
     bound = 1024 * 2.4e9 / (instr * 4.0)
@@ -200,8 +200,8 @@ def decoder_under_load(dtl, device, arith, ncw=1 << 20, esn0_db=-1.0, reps=3):
 
 
 # wave instructions in one belief-propagation iteration of ldpc_bp_np_kernel<6,3,5,true,*> (tools/isa_loops.py on the
-# built code object; profiles/r02/ldpc_isa_counts.txt)
-LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 960, "fast": 706}
+# built code object; profiles/r03/ldpc_isa_counts.txt)
+LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 1075, "fast": 750}
 
 
 def timed_steps(rx, x, steps, warmup, barrier):

@@ -313,15 +313,16 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
 #if DTL_ABLATE == 21
         return __ballot(X[0] == 0xdeadbeefull) == 0ull;
 #endif
-        unsigned bad = 0;
+        // (a pass of 64 checks at a time, left at the first pass that holds an unsatisfied check: while a codeword has not
+        // converged that is nearly always the first one)
         for (int c0 = 0; c0 < t.m; c0 += kWave) {
             const int c = min(c0 + lane, t.m - 1);        // (a lane past the last check repeats it)
             unsigned long long fold = 0;
 #pragma unroll
             for (int p = 0; p < NV; p++) fold ^= chk_bits[c * (NV | 1) + p] & X[p];
-            bad |= unsigned(__popc(unsigned(fold) ^ unsigned(fold >> 32))) & 1u;
+            if (__ballot((__popc(unsigned(fold) ^ unsigned(fold >> 32)) & 1) != 0) != 0ull) return false;
         }
-        return __ballot(bad != 0) == 0ull;
+        return true;
     };
     // The memory pipeline of a wave: while codeword i is decoded, the soft bits of i + 1 are in flight and the
     // descriptor of i + 2 is being read -- through the SCALAR cache, as five whole dwords, so that waiting for it never
@@ -628,8 +629,12 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                     // lane's reads of a pass precede its writes (one wave, program order), and the slot is set back to
                     // 1.0 behind the writes of each pass (one uniform store instead of a compare + select per entry)
                     unsigned char* msg_b = reinterpret_cast<unsigned char*>(msg);
-                    unsigned dec = 0;                     // bit p: decision of variable lane + 64 p
-                    for (int p = 0, v = lane; v < t.n; p++, v += kWave) {
+                    // (unrolled over the NV passes: the decisions of pass p are the compare's own result, word X[p])
+#pragma unroll
+                    for (int p = 0; p < NV; p++) {
+                        const int v = lane + p * kWave;
+                        bool one = false;
+                        if (v < t.n) {
                         const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
                         int ee[MAXC];
                         double rr[MAXC];
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                             for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
 #pragma unroll
                             for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = pre[i] * suf[i];
-                            dec |= (pre[MAXC] > 1 ? 1u : 0u) << p;
+                            one = pre[MAXC] > 1;
                         } else {
                             double sum = rx[v];
 #pragma unroll
@@ -659,13 +664,13 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                             }
 #pragma unroll
                             for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = div_exact<TAME>(sum, rr[i]);
-                            dec |= (sum > 1 ? 1u : 0u) << p;
+                            one = sum > 1;
                         }
                         msg[kOneSlot] = 1.0;
+                        }
+                        X[p] = __ballot(one);
                     }
                     wave_sync();
-#pragma unroll
-                    for (int p = 0; p < NV; p++) X[p] = __ballot(((dec >> p) & 1u) != 0);
                     if (syndrome_ok(X)) break;
                 }
             };
