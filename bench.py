@@ -201,7 +201,7 @@ def decoder_under_load(dtl, device, arith, ncw=1 << 20, esn0_db=-1.0, reps=3):
 
 # wave instructions in one belief-propagation iteration of ldpc_bp_np_kernel<6,3,5,true,*> (tools/isa_loops.py on the
 # built code object; profiles/r03/ldpc_isa_counts.txt)
-LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 1075, "fast": 750}
+LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 965, "fast": 665}
 
 
 def timed_steps(rx, x, steps, warmup, barrier):
