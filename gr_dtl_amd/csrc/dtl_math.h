@@ -41,6 +41,62 @@ __device__ __forceinline__ float dm_exp(float x)
     return (x != x) ? x : res;
 }
 
+// Two values at a time (v_pk_mul_f32 / v_pk_fma_f32: one instruction, two IEEE operations): the sequences of
+// dm_neg_div_by<true> and dm_exp<true> applied to both components -- for waves whose operands are ordinary (the demapper's
+// ORD form), where neither has a special case left except the exponential's underflow clamp.
+typedef float dm_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ dm_f2 dm_fma2(dm_f2 a, dm_f2 b, dm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// exp(-a / b) for K pairs at once, the K chains written side by side (every packed instruction then has K - 1 independent
+// ones between itself and its consumer: no wait states between dependent packed operations)
+template <int K>
+__device__ __forceinline__ void dm_exp_neg_div_by_pairs(const dm_f2 (&a)[K], float b, float r, dm_f2 (&out)[K])
+{
+    const dm_f2 bb = { b, b }, rr = { r, r };
+    dm_f2 q[K], e[K], x[K], kf[K], p[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) q[i] = a[i] * rr;
+#pragma unroll
+    for (int i = 0; i < K; i++) e[i] = dm_fma2(-bb, q[i], a[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) q[i] = dm_fma2(e[i], rr, q[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) e[i] = dm_fma2(-bb, q[i], a[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) x[i] = -dm_fma2(e[i], rr, q[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const dm_f2 t = x[i] * dm_f2{ 1.44269504f, 1.44269504f };
+        kf[i] = dm_f2{ rintf(t.x), rintf(t.y) };
+    }
+#pragma unroll
+    for (int i = 0; i < K; i++) e[i] = dm_fma2(-kf[i], dm_f2{ 0.693145752f, 0.693145752f }, x[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) e[i] = dm_fma2(-kf[i], dm_f2{ 1.42860677e-06f, 1.42860677e-06f }, e[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) p[i] = dm_fma2(dm_f2{ 1.9841270e-4f, 1.9841270e-4f }, e[i], dm_f2{ 1.3888889e-3f, 1.3888889e-3f });
+#pragma unroll
+    for (int i = 0; i < K; i++) p[i] = dm_fma2(p[i], e[i], dm_f2{ 8.3333338e-3f, 8.3333338e-3f });
+#pragma unroll
+    for (int i = 0; i < K; i++) p[i] = dm_fma2(p[i], e[i], dm_f2{ 4.1666668e-2f, 4.1666668e-2f });
+#pragma unroll
+    for (int i = 0; i < K; i++) p[i] = dm_fma2(p[i], e[i], dm_f2{ 1.6666667e-1f, 1.6666667e-1f });
+#pragma unroll
+    for (int i = 0; i < K; i++) p[i] = dm_fma2(p[i], e[i], dm_f2{ 0.5f, 0.5f });
+#pragma unroll
+    for (int i = 0; i < K; i++) p[i] = dm_fma2(p[i], e[i], dm_f2{ 1.0f, 1.0f });
+#pragma unroll
+    for (int i = 0; i < K; i++) p[i] = dm_fma2(p[i], e[i], dm_f2{ 1.0f, 1.0f });
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        dm_f2 res = { ldexpf(p[i].x, int(kf[i].x)), ldexpf(p[i].y, int(kf[i].y)) };
+        res.x = (x[i].x < -103.97208f) ? 0.0f : res.x;
+        res.y = (x[i].y < -103.97208f) ? 0.0f : res.y;
+        out[i] = res;
+    }
+}
+
 // exp(x) in double with the same construction (k = rint(x log2e), r = x - k ln2 with fdlibm's hi/lo split, Taylor
 // polynomial of degree 13 in Horner form, 2^k applied last); < 1 ulp.  The LDPC decoder's channel likelihood ratios use
 // it instead of the library exp, whose last bit is the library's own (ocml and glibc differ at x = 40): the CPU oracle

@@ -872,12 +872,24 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
     constexpr bool PLAIN_DIST = MODE == 1;
     if constexpr (BPS == 4 && MODE == 2) {
         float er[4], ei[4];
+        if constexpr (ORD) {
+            dm_f2 d2[4], ex[4];                           // (real level, imaginary level) pairs through the packed instructions
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float dr = s.re - pts[q << 1].re, di = s.im - pts[(q & 1) | ((q >> 1) << 3)].im;
+                d2[q] = dm_f2{ dr * dr, di * di };
+            }
+            dm_exp_neg_div_by_pairs<4>(d2, npwr, rinv, ex);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { er[q] = ex[q].x; ei[q] = ex[q].y; }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const float dr = s.re - pts[q << 1].re;                        // points 0, 2, 4, 6: the four real levels
             const float di = s.im - pts[(q & 1) | ((q >> 1) << 3)].im;     // points 0, 1, 8, 9: the four imaginary levels
             er[q] = dm_exp<ORD>(dm_neg_div_by<ORD>(dr * dr, npwr, rinv));
             ei[q] = dm_exp<ORD>(dm_neg_div_by<ORD>(di * di, npwr, rinv));
+        }
         }
         // index bit 1 / 2 = LSB / MSB of the real level, bit 0 / 3 = LSB / MSB of the imaginary level; LSB first
         const float a1[4] = { ei[1] + ei[3], er[1] + er[3], er[2] + er[3], ei[2] + ei[3] };
@@ -903,8 +915,7 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
             di2[q] = di * di;
         }
     }
-#pragma unroll
-    for (int m = 0; m < M; m++) {
+    auto distance = [&](int m) -> float {
         float sq;
         if (BPS == 4) {
             sq = dr2[(m >> 1) & 3] + di2[(m & 1) | ((m >> 3) << 1)];
@@ -913,12 +924,38 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
             sq = dr * dr + di * di;
         }
         // compile-time switch: a runtime select would evaluate the correctly rounded sqrtf for every point
-        const float dist = PLAIN_DIST ? sqrtf(sq) : sq;
-        const float d = dm_exp<ORD>(dm_neg_div_by<ORD>(dist, npwr, rinv)); // -dist / npwr exactly; fixed-sequence expf (dtl_math.h)
+        return PLAIN_DIST ? sqrtf(sq) : sq;
+    };
+    if constexpr (ORD && M >= 2) {
+        // two points per step through the packed instructions (same operations per point, same order of the sums)
+        constexpr int K = M >= 8 ? 4 : M / 2;            // pairs per step
 #pragma unroll
-        for (int j = 0; j < BPS; j++) {
-            if ((m >> j) & 1) p1[j] += d;
-            else p0[j] += d;
+        for (int m0 = 0; m0 < M; m0 += 2 * K) {
+            dm_f2 dist2[K], d[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) dist2[i] = dm_f2{ distance(m0 + 2 * i), distance(m0 + 2 * i + 1) };
+            dm_exp_neg_div_by_pairs<K>(dist2, npwr, rinv, d);
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const int m = m0 + 2 * i;
+#pragma unroll
+                for (int j = 0; j < BPS; j++) {
+                    if ((m >> j) & 1) p1[j] += d[i].x;
+                    else p0[j] += d[i].x;
+                    if (((m + 1) >> j) & 1) p1[j] += d[i].y;
+                    else p0[j] += d[i].y;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const float d = dm_exp<ORD>(dm_neg_div_by<ORD>(distance(m), npwr, rinv)); // -dist / npwr exactly; fixed-sequence expf (dtl_math.h)
+#pragma unroll
+            for (int j = 0; j < BPS; j++) {
+                if ((m >> j) & 1) p1[j] += d;
+                else p0[j] += d;
+            }
         }
     }
     demap_log_ratios<BPS, ORD>(p1, p0, o);
