@@ -1715,17 +1715,29 @@ __global__ __launch_bounds__(64) void expand_cw_kernel(const TbGather* __restric
     }
 }
 
-// Exclusive scan of the per-block output lengths (single workgroup; block counts are O(frames)).
+// Exclusive scan of the per-block output lengths (single workgroup; block counts are O(frames)).  Every thread owns a run
+// of consecutive entries, a multiple of four, read and written as 16-byte vectors with the loads of a run issued
+// together (one entry per load, each waited for in turn, was 126 serial memory round trips per thread: 0.095 ms for
+// 64 k blocks).
 __global__ __launch_bounds__(1024) void scan_lengths_kernel(const int32_t* __restrict__ len, int n,
                                                            uint32_t* __restrict__ offs,
                                                            uint32_t* __restrict__ total)
 {
     __shared__ uint32_t part[1024];
     const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = tid * per, hi = min(n, lo + per);
+    const int per = ((n + 1023) / 1024 + 3) & ~3;
+    const int lo = min(n, tid * per), hi = min(n, lo + per);
+    const bool vec = (reinterpret_cast<uintptr_t>(len) & 15) == 0 && (reinterpret_cast<uintptr_t>(offs) & 15) == 0;
     uint32_t s = 0;
-    for (int i = lo; i < hi; i++) s += uint32_t(len[i]);
+    int i = lo;
+    if (vec) {
+#pragma unroll 4
+        for (; i + 4 <= hi; i += 4) {
+            const int4 v = *reinterpret_cast<const int4*>(len + i);
+            s += uint32_t(v.x) + uint32_t(v.y) + uint32_t(v.z) + uint32_t(v.w);
+        }
+    }
+    for (; i < hi; i++) s += uint32_t(len[i]);
     part[tid] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -1735,7 +1747,20 @@ __global__ __launch_bounds__(1024) void scan_lengths_kernel(const int32_t* __res
         __syncthreads();
     }
     uint32_t run = part[tid] - s;
-    for (int i = lo; i < hi; i++) { offs[i] = run; run += uint32_t(len[i]); }
+    i = lo;
+    if (vec) {
+#pragma unroll 4
+        for (; i + 4 <= hi; i += 4) {
+            const int4 v = *reinterpret_cast<const int4*>(len + i);
+            uint4 o;
+            o.x = run; run += uint32_t(v.x);
+            o.y = run; run += uint32_t(v.y);
+            o.z = run; run += uint32_t(v.z);
+            o.w = run; run += uint32_t(v.w);
+            *reinterpret_cast<uint4*>(offs + i) = o;
+        }
+    }
+    for (; i < hi; i++) { offs[i] = run; run += uint32_t(len[i]); }
     if (tid == 1023) *total = part[1023];
 }
 
