@@ -156,3 +156,33 @@ def test_gather_descriptors_partial_reception(oracle, dtl, cuda, alist, arith):
         np.testing.assert_array_equal(got[o:o + k_useds[i]], ref_bits[i, :k_useds[i]], err_msg=f"codeword {i}")
         o += k_useds[i]
     assert (ref_nit == 0).mean() > 0.1 and (ref_nit > 0).mean() > 0.2
+
+
+@pytest.mark.gpu
+def test_every_batch_size_is_decoded_once(oracle, dtl, cuda):
+    """The decoder's work queue (chunks dealt round-robin to eight ticket counters, big chunks first, two-codeword
+    chunks at the end, the next ticket requested a chunk ahead): every codeword of a batch is decoded exactly once
+    whatever the batch size -- fewer codewords than counters, than waves, than one chunk per wave, one more or less
+    than a multiple of the chunk sizes."""
+    import torch
+    code = oracle.Ldpc(ALIST_300)
+    dec = dtl.ldpc_dec(ALIST_300)
+    sizes = [1, 2, 3, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 12287, 12289, 32769, 65537, 200001]
+    data, llr = _noisy_llrs(code, max(sizes), 5.0, seed=77)   # ~15 % of the codewords need no iteration
+    ref_bits, ref_nit = oracle.Ldpc.decode_batch(code, llr[:8192], n_threads=8)
+    d_llr = torch.from_numpy(llr).to(cuda)
+    full_bits = full_nit = None
+    for n in reversed(sizes):
+        bits = torch.full((n, code.k), 9, dtype=torch.uint8, device=cuda)
+        nit = torch.full((n,), -7, dtype=torch.int32, device=cuda)
+        dec.decode_batch(d_llr[:n], bits, nit)
+        bits, nit = bits.cpu().numpy(), nit.cpu().numpy()
+        if full_bits is None:
+            full_bits, full_nit = bits, nit               # the largest batch: checked against the oracle on its first 8192 ...
+            np.testing.assert_array_equal(nit[:8192], ref_nit)
+            np.testing.assert_array_equal(bits[:8192], ref_bits)
+            assert (nit >= 0).all() and (bits <= 1).all()
+            assert 0.05 < (nit == 0).mean() < 0.95
+        else:                                             # ... and every smaller one against its prefix
+            np.testing.assert_array_equal(nit, full_nit[:n], err_msg=f"batch of {n}")
+            np.testing.assert_array_equal(bits, full_bits[:n], err_msg=f"batch of {n}")
