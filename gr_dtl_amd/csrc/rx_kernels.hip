@@ -1061,7 +1061,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
                                 const FrameDesc* __restrict__ frames, const CfoSegment* __restrict__ segs,
                                 int n_segs, const cf32* __restrict__ taps_in, FrameStat* __restrict__ stats,
                                 cf32* __restrict__ eq_hard, cf32* __restrict__ eq_soft,
-                                cf32* __restrict__ soft_syms, float* __restrict__ llr_out = nullptr, int rho0 = 0)
+                                cf32* __restrict__ soft_syms, float* __restrict__ llr_out = nullptr, int rho0 = 0,
+                                FrameDesc* __restrict__ frames_copy = nullptr)
 {
     static_assert(DEMAP < 0 || (STAGED && !FREQ_IN), "the fused demapper belongs to the staged receive-path form");
     constexpr bool FUSED = DEMAP >= 0;
@@ -1082,7 +1083,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
     [[maybe_unused]] const int n_lds = rho0 + 1;      // FUSED: destination symbols i < n_lds are parked in LDS
     tw[tid] = t.twiddle[tid];
 
+    // (`frames` may be the host's pinned, coherent copy of the descriptors, read here once per workgroup; the kernels
+    // behind this one read `frames_copy` in device memory)
     const FrameDesc fd = frames[blockIdx.x];
+    if (frames_copy && threadIdx.x == 0) frames_copy[blockIdx.x] = fd;
     const int off = fd.carr_offset;
     const int total = L * N;
     const SegWindow sw = seg_window(segs, n_segs, fd.seg);
@@ -1969,9 +1973,15 @@ bool payload_is_fused(const RxTables& t, bool eq_rows)
 int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
                    const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
                    float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
-                   uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st)
+                   uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st,
+                   const FrameDesc* frames_host)
 {
     if (n_frames <= 0) return DTL_OK;
+    // frames_host: the descriptors in pinned, coherent host memory -- the frame equaliser reads them from there (32 bytes
+    // per workgroup) and leaves the copy in `frames` for the kernels behind it: no host-to-device copy in the stream (every
+    // small copy behind a kernel costs ~12 us of device idle plus its own time)
+    const FrameDesc* src = frames_host ? frames_host : frames;
+    FrameDesc* copy = frames_host ? const_cast<FrameDesc*>(frames) : nullptr;
     const bool eq_rows = eq_hard || eq_soft;
     const bool staged = payload_staged(t, eq_rows);
     const bool fused = payload_is_fused(t, eq_rows);
@@ -1983,23 +1993,23 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
     if (fused) {
         cf32* ss = soft_syms_wanted ? soft_syms : nullptr;
         if (mode == 1)
-            hipLaunchKernelGGL((frame_eq_kernel<true, false, 1>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
-                               taps, stats, eq_hard, eq_soft, ss, llr, rho0);
+            hipLaunchKernelGGL((frame_eq_kernel<true, false, 1>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, src, segs, n_segs,
+                               taps, stats, eq_hard, eq_soft, ss, llr, rho0, copy);
         else if (mode == 2)
-            hipLaunchKernelGGL((frame_eq_kernel<true, false, 2>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
-                               taps, stats, eq_hard, eq_soft, ss, llr, rho0);
+            hipLaunchKernelGGL((frame_eq_kernel<true, false, 2>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, src, segs, n_segs,
+                               taps, stats, eq_hard, eq_soft, ss, llr, rho0, copy);
         else
-            hipLaunchKernelGGL((frame_eq_kernel<true, false, 0>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs,
-                               taps, stats, eq_hard, eq_soft, ss, llr, rho0);
+            hipLaunchKernelGGL((frame_eq_kernel<true, false, 0>), dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, src, segs, n_segs,
+                               taps, stats, eq_hard, eq_soft, ss, llr, rho0, copy);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
     }
     if (staged)
-        hipLaunchKernelGGL(frame_eq_kernel<true>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
-                           stats, eq_hard, eq_soft, soft_syms, nullptr, 0);
+        hipLaunchKernelGGL(frame_eq_kernel<true>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, src, segs, n_segs, taps,
+                           stats, eq_hard, eq_soft, soft_syms, nullptr, 0, copy);
     else
-        hipLaunchKernelGGL(frame_eq_kernel<false>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, frames, segs, n_segs, taps,
-                           stats, eq_hard, eq_soft, soft_syms, nullptr, 0);
+        hipLaunchKernelGGL(frame_eq_kernel<false>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, src, segs, n_segs, taps,
+                           stats, eq_hard, eq_soft, soft_syms, nullptr, 0, copy);
     if (t.has_fec) {
         const dim3 grid(n_frames, (t.frame_capacity + 255) / 256);
         if (mode == 1) hipLaunchKernelGGL(demap_kernel<1>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr);

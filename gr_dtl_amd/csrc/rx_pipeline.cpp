@@ -50,11 +50,21 @@ HostBuf::~HostBuf()
 
 int HostBuf::ensure(size_t bytes)
 {
-    if (bytes <= cap && p) return DTL_OK;
+    if (bytes <= cap && p && (mapped_coherent || !device_reads)) return DTL_OK;
+    bytes = std::max(bytes, cap);                         // (a buffer that only changes its mapping keeps its size)
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    DTL_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    // device_reads: kernels read the buffer in place -- fine-grained (coherent) mapping, never cached on the device
+    DTL_HIP_CHECK(hipHostMalloc(&p, want, device_reads ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault));
+    mapped_coherent = device_reads;
     cap = want;
+    return DTL_OK;
+}
+
+// the address kernels use for a buffer they read in place (HostBuf::device_reads)
+static int device_view(const HostBuf& hb, void** out)
+{
+    DTL_HIP_CHECK(hipHostGetDevicePointer(out, hb.p, 0));
     return DTL_OK;
 }
 
@@ -524,6 +534,7 @@ Receiver::Receiver() : ss_(std::make_unique<StreamState>())
     // tests lower the threshold so that small streams take the pipelined (four ranges, early header launches) path
     if (const char* e = getenv("DTL_RX_SPLIT_MIN")) split_min_ = std::max<int64_t>(1, atoll(e));
     if (const char* e = getenv("DTL_RX_SYNC_RANGES")) sync_ranges_ = std::min(16, std::max(1, atoi(e)));
+    if (const char* e = getenv("DTL_RX_ZERO_COPY_DESCS")) zero_copy_descs_ = atoi(e) != 0;
     if (const char* e = getenv("DTL_RX_FLUSH_FRAMES")) flush_frames_ = std::max(64, atoi(e));   // (tuning experiments)
     if (const char* e = getenv("DTL_RX_FLUSH_FIRST")) flush_first_ = std::max(64, atoi(e));
 }
@@ -1112,6 +1123,7 @@ int Receiver::submit_angles(Call& c, size_t first, size_t count, hipStream_t on)
         // growing the buffers discards them: take what is in flight first
         DTL_TRY(collect_angles(c, c.angle_parts.size()));
         const size_t want = std::max<size_t>(2 * need, size_t(2 * (c.W / frame_samples() + 1) + 1024));
+        h_trig_.device_reads = zero_copy_descs_;
         DTL_TRY(h_trig_.ensure(want * 8));
         DTL_TRY(d_trig_.ensure(want * 8));
         DTL_TRY(d_angle_.ensure(want * 4));
@@ -1119,8 +1131,15 @@ int Receiver::submit_angles(Call& c, size_t first, size_t count, hipStream_t on)
     }
     int64_t* rel = h_trig_.as<int64_t>() + first;
     for (size_t j = 0; j < count; j++) rel[j] = raw_triggers[first + j] - c.A;
-    DTL_HIP_CHECK(hipMemcpyAsync(d_trig_.as<int64_t>() + first, rel, count * 8, hipMemcpyHostToDevice, on));
-    DTL_TRY(launch_trigger_angle(c.iq, c.W, c.N, d_trig_.as<int64_t>() + first, int(count), d_angle_.as<float>() + first, on));
+    const int64_t* trig_dev = d_trig_.as<int64_t>() + first;
+    if (zero_copy_descs_) {                               // one 8-byte read per trigger, in place
+        void* dp = nullptr;
+        DTL_TRY(device_view(h_trig_, &dp));
+        trig_dev = static_cast<const int64_t*>(dp) + first;
+    } else {
+        DTL_HIP_CHECK(hipMemcpyAsync(d_trig_.as<int64_t>() + first, rel, count * 8, hipMemcpyHostToDevice, on));
+    }
+    DTL_TRY(launch_trigger_angle(c.iq, c.W, c.N, trig_dev, int(count), d_angle_.as<float>() + first, on));
     DTL_HIP_CHECK(hipMemcpyAsync(h_angle_.as<float>() + first, d_angle_.as<float>() + first, count * 4, hipMemcpyDeviceToHost, on));
     const size_t part = c.angle_parts.size();
     while (angle_ev_.size() <= part) {
@@ -1217,6 +1236,7 @@ int Receiver::speculate_headers(Call& c, int64_t limit, bool split_last)
         const size_t cap = size_t(2 * (c.W / frame_samples() + 1) + 1024);
         const size_t seg_cap = ss.segs.size() + cap;
         DTL_TRY(d_cands_.ensure(cap * sizeof(Candidate)));
+        h_cands_.device_reads = zero_copy_descs_;
         DTL_TRY(h_cands_.ensure(cap * sizeof(Candidate)));
         DTL_TRY(d_segs_.ensure(seg_cap * sizeof(CfoSegment)));
         DTL_TRY(h_segs_.ensure(seg_cap * sizeof(CfoSegment)));
@@ -1233,8 +1253,15 @@ int Receiver::speculate_headers(Call& c, int64_t limit, bool split_last)
         return DTL_OK;
     }
     std::memcpy(h_cands_.as<Candidate>() + s0, add.data(), add.size() * sizeof(Candidate));
-    DTL_HIP_CHECK(hipMemcpyAsync(d_cands_.as<Candidate>() + s0, h_cands_.as<Candidate>() + s0, add.size() * sizeof(Candidate),
-                                 hipMemcpyHostToDevice, c.st));
+    const Candidate* cands_dev = d_cands_.as<Candidate>();
+    if (zero_copy_descs_) {                               // one 16-byte read per header workgroup, in place
+        void* dp = nullptr;
+        DTL_TRY(device_view(h_cands_, &dp));
+        cands_dev = static_cast<const Candidate*>(dp);
+    } else {
+        DTL_HIP_CHECK(hipMemcpyAsync(d_cands_.as<Candidate>() + s0, h_cands_.as<Candidate>() + s0, add.size() * sizeof(Candidate),
+                                     hipMemcpyHostToDevice, c.st));
+    }
     if (segs_now > c.segs_uploaded) {
         CfoSegment* hs = h_segs_.as<CfoSegment>();
         for (size_t k = c.segs_uploaded; k < segs_now; k++) { hs[k] = ss.segs[k]; hs[k].start -= c.A; }
@@ -1250,7 +1277,7 @@ int Receiver::speculate_headers(Call& c, int64_t limit, bool split_last)
         const int e0 = int(int64_t(n_add) * part / n_parts), e1 = int(int64_t(n_add) * (part + 1) / n_parts);
         if (e1 <= e0) continue;
         const size_t p0 = s0 + size_t(e0);
-        DTL_TRY(launch_header(tab_, c.iq, c.W, d_cands_.as<Candidate>() + p0, e1 - e0, d_segs_.as<CfoSegment>(),
+        DTL_TRY(launch_header(tab_, c.iq, c.W, cands_dev + p0, e1 - e0, d_segs_.as<CfoSegment>(),
                               int(c.segs_uploaded), d_recs_.as<HeaderRec>() + p0, d_taps.as<cf32>() + p0 * N,
                               hb ? hb + p0 * tab_.hdr_bits : nullptr, c.st));
         DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + p0, d_recs_.as<HeaderRec>() + p0, size_t(e1 - e0) * sizeof(HeaderRec),
@@ -1455,6 +1482,7 @@ int Receiver::stage_frames(Call& c)
         for (size_t e = 0; e < extra.size(); e++) slot[extra[e]] = int(s_base + e);
         recs.resize(n_slots);
         DTL_TRY(d_cands_.ensure(n_slots * sizeof(Candidate)));
+        h_cands_.device_reads = zero_copy_descs_;
         DTL_TRY(h_cands_.ensure(n_slots * sizeof(Candidate)));
         DTL_TRY(d_segs_.ensure(std::max<size_t>(1, n_segs_all) * sizeof(CfoSegment)));
         DTL_TRY(h_segs_.ensure(std::max<size_t>(1, n_segs_all) * sizeof(CfoSegment)));
@@ -1470,6 +1498,7 @@ int Receiver::stage_frames(Call& c)
             DTL_HIP_CHECK(hipMemcpyAsync(d_llr.p, d_llr_carry_.p, size_t(ss.llr_carry_len) * 4, hipMemcpyDeviceToDevice, st));
         DTL_TRY(d_stats_.ensure(size_t(n_cand) * sizeof(FrameStat)));
         DTL_TRY(d_frames_.ensure(size_t(n_cand) * sizeof(FrameDesc)));
+        h_frames_.device_reads = zero_copy_descs_;
         DTL_TRY(h_frames_.ensure(size_t(n_cand) * sizeof(FrameDesc)));
         if (flags & RX_WANT_EQ_HARD) { DTL_TRY(d_eq_hard.ensure(size_t(n_cand) * L * N * sizeof(cf32))); eh = d_eq_hard.as<cf32>(); }
         if (flags & RX_WANT_EQ_SOFT) { DTL_TRY(d_eq_soft.ensure(size_t(n_cand) * L * N * sizeof(cf32))); es = d_eq_soft.as<cf32>(); }
@@ -1499,13 +1528,20 @@ int Receiver::stage_frames(Call& c)
         if (!extra.empty()) {
             Candidate* hc = h_cands_.as<Candidate>() + s_base;
             for (size_t e = 0; e < extra.size(); e++) hc[e] = cands[extra[e]];
-            DTL_HIP_CHECK(hipMemcpyAsync(d_cands_.as<Candidate>() + s_base, hc, extra.size() * sizeof(Candidate), hipMemcpyHostToDevice, st));
+            const Candidate* cands_dev = d_cands_.as<Candidate>();
+            if (zero_copy_descs_) {
+                void* dp = nullptr;
+                DTL_TRY(device_view(h_cands_, &dp));
+                cands_dev = static_cast<const Candidate*>(dp);
+            } else {
+                DTL_HIP_CHECK(hipMemcpyAsync(d_cands_.as<Candidate>() + s_base, hc, extra.size() * sizeof(Candidate), hipMemcpyHostToDevice, st));
+            }
             const int n_extra = int(extra.size()), n_parts = n_extra >= 8192 ? 4 : 1;
             for (int part = 0; part < n_parts; part++) {
                 const int e0 = int(int64_t(n_extra) * part / n_parts), e1 = int(int64_t(n_extra) * (part + 1) / n_parts);
                 if (e1 <= e0) continue;
                 const size_t s0 = s_base + size_t(e0);
-                DTL_TRY(launch_header(tab_, iq, W, d_cands_.as<Candidate>() + s0, e1 - e0, d_segs_.as<CfoSegment>(), n_segs,
+                DTL_TRY(launch_header(tab_, iq, W, cands_dev + s0, e1 - e0, d_segs_.as<CfoSegment>(), n_segs,
                                       d_recs_.as<HeaderRec>() + s0, d_taps.as<cf32>() + s0 * N,
                                       hb ? hb + s0 * tab_.hdr_bits : nullptr, st));
                 DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + s0, d_recs_.as<HeaderRec>() + s0,
@@ -1528,16 +1564,25 @@ int Receiver::stage_frames(Call& c)
     auto flush_payload = [&]() -> int {
         const int f1 = int(fdesc.size());
         if (f1 <= f0) return DTL_OK;
+        // the descriptors stay where the host wrote them: the frame equaliser reads them there (zero_copy_descs_) and
+        // leaves the device copy the demapper reads
         std::memcpy(h_frames_.as<FrameDesc>() + f0, fdesc.data() + f0, size_t(f1 - f0) * sizeof(FrameDesc));
-        DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.as<FrameDesc>() + f0, h_frames_.as<FrameDesc>() + f0,
-                                     size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        const FrameDesc* host_descs = nullptr;
+        if (zero_copy_descs_) {
+            void* dp = nullptr;
+            DTL_HIP_CHECK(hipHostGetDevicePointer(&dp, h_frames_.p, 0));
+            host_descs = static_cast<const FrameDesc*>(dp) + f0;
+        } else {
+            DTL_HIP_CHECK(hipMemcpyAsync(d_frames_.as<FrameDesc>() + f0, h_frames_.as<FrameDesc>() + f0,
+                                         size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        }
         if (!payload_started && ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
         DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
                                d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0,
                                d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
                                ss_out ? ss_out + size_t(f0) * capacity_ : nullptr, (flags & RX_WANT_SOFT_SYMS) != 0,
                                nofec_bytes ? nofec_bytes + size_t(f0) * nofec_stride : nullptr,
-                               nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st));
+                               nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st, host_descs));
         f0 = f1;
         return DTL_OK;
     };

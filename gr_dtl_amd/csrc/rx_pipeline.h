@@ -118,6 +118,8 @@ struct DevBuf {
 struct HostBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool device_reads = false;  // set before ensure(): kernels read the buffer in place (coherent mapping)
+    bool mapped_coherent = false;
     ~HostBuf();
     int ensure(size_t bytes);
     template <typename T> T* as() const { return static_cast<T*>(p); }
@@ -213,6 +215,7 @@ private:
     hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
     std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers
     std::vector<hipEvent_t> hdr_ev_;   // one per header-kernel launch of a call
+    bool zero_copy_descs_ = true;  // phase B reads the frame descriptors from pinned host memory (DTL_RX_ZERO_COPY_DESCS=0: copies)
     int flush_first_ = 2048, flush_frames_ = 8192; // phase B is handed over after this many frames of the demux walk (first / later hand-overs)
     int64_t split_min_ = int64_t(1) << 26; // calls with at least this many new samples run the sync stage in several ranges
     int sync_ranges_ = 4;                  // measured: 4 -> 17.7 ms per C3 step, 6 -> 17.8, 8 -> 18.1 (per-range launch and copy overhead)
