@@ -535,6 +535,8 @@ Receiver::Receiver() : ss_(std::make_unique<StreamState>())
     if (const char* e = getenv("DTL_RX_SPLIT_MIN")) split_min_ = std::max<int64_t>(1, atoll(e));
     if (const char* e = getenv("DTL_RX_SYNC_RANGES")) sync_ranges_ = std::min(16, std::max(1, atoi(e)));
     if (const char* e = getenv("DTL_RX_ZERO_COPY_DESCS")) zero_copy_descs_ = atoi(e) != 0;
+    if (const char* e = getenv("DTL_RX_ZERO_COPY_CANDS")) zero_copy_cands_ = atoi(e) != 0;
+    if (const char* e = getenv("DTL_RX_ZERO_COPY_TRIG")) zero_copy_trig_ = atoi(e) != 0;
     if (const char* e = getenv("DTL_RX_FLUSH_FRAMES")) flush_frames_ = std::max(64, atoi(e));   // (tuning experiments)
     if (const char* e = getenv("DTL_RX_FLUSH_FIRST")) flush_first_ = std::max(64, atoi(e));
 }
@@ -1123,7 +1125,7 @@ int Receiver::submit_angles(Call& c, size_t first, size_t count, hipStream_t on)
         // growing the buffers discards them: take what is in flight first
         DTL_TRY(collect_angles(c, c.angle_parts.size()));
         const size_t want = std::max<size_t>(2 * need, size_t(2 * (c.W / frame_samples() + 1) + 1024));
-        h_trig_.device_reads = zero_copy_descs_;
+        h_trig_.device_reads = zero_copy_trig_;
         DTL_TRY(h_trig_.ensure(want * 8));
         DTL_TRY(d_trig_.ensure(want * 8));
         DTL_TRY(d_angle_.ensure(want * 4));
@@ -1132,7 +1134,7 @@ int Receiver::submit_angles(Call& c, size_t first, size_t count, hipStream_t on)
     int64_t* rel = h_trig_.as<int64_t>() + first;
     for (size_t j = 0; j < count; j++) rel[j] = raw_triggers[first + j] - c.A;
     const int64_t* trig_dev = d_trig_.as<int64_t>() + first;
-    if (zero_copy_descs_) {                               // one 8-byte read per trigger, in place
+    if (zero_copy_trig_) {                                // one 8-byte read per trigger, in place
         void* dp = nullptr;
         DTL_TRY(device_view(h_trig_, &dp));
         trig_dev = static_cast<const int64_t*>(dp) + first;
@@ -1236,7 +1238,7 @@ int Receiver::speculate_headers(Call& c, int64_t limit, bool split_last)
         const size_t cap = size_t(2 * (c.W / frame_samples() + 1) + 1024);
         const size_t seg_cap = ss.segs.size() + cap;
         DTL_TRY(d_cands_.ensure(cap * sizeof(Candidate)));
-        h_cands_.device_reads = zero_copy_descs_;
+        h_cands_.device_reads = zero_copy_cands_;
         DTL_TRY(h_cands_.ensure(cap * sizeof(Candidate)));
         DTL_TRY(d_segs_.ensure(seg_cap * sizeof(CfoSegment)));
         DTL_TRY(h_segs_.ensure(seg_cap * sizeof(CfoSegment)));
@@ -1254,7 +1256,7 @@ int Receiver::speculate_headers(Call& c, int64_t limit, bool split_last)
     }
     std::memcpy(h_cands_.as<Candidate>() + s0, add.data(), add.size() * sizeof(Candidate));
     const Candidate* cands_dev = d_cands_.as<Candidate>();
-    if (zero_copy_descs_) {                               // one 16-byte read per header workgroup, in place
+    if (zero_copy_cands_) {                               // one 16-byte read per header workgroup, in place
         void* dp = nullptr;
         DTL_TRY(device_view(h_cands_, &dp));
         cands_dev = static_cast<const Candidate*>(dp);
@@ -1482,7 +1484,7 @@ int Receiver::stage_frames(Call& c)
         for (size_t e = 0; e < extra.size(); e++) slot[extra[e]] = int(s_base + e);
         recs.resize(n_slots);
         DTL_TRY(d_cands_.ensure(n_slots * sizeof(Candidate)));
-        h_cands_.device_reads = zero_copy_descs_;
+        h_cands_.device_reads = zero_copy_cands_;
         DTL_TRY(h_cands_.ensure(n_slots * sizeof(Candidate)));
         DTL_TRY(d_segs_.ensure(std::max<size_t>(1, n_segs_all) * sizeof(CfoSegment)));
         DTL_TRY(h_segs_.ensure(std::max<size_t>(1, n_segs_all) * sizeof(CfoSegment)));
@@ -1529,7 +1531,7 @@ int Receiver::stage_frames(Call& c)
             Candidate* hc = h_cands_.as<Candidate>() + s_base;
             for (size_t e = 0; e < extra.size(); e++) hc[e] = cands[extra[e]];
             const Candidate* cands_dev = d_cands_.as<Candidate>();
-            if (zero_copy_descs_) {
+            if (zero_copy_cands_) {
                 void* dp = nullptr;
                 DTL_TRY(device_view(h_cands_, &dp));
                 cands_dev = static_cast<const Candidate*>(dp);

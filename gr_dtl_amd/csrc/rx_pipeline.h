@@ -215,6 +215,9 @@ private:
     hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
     std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers
     std::vector<hipEvent_t> hdr_ev_;   // one per header-kernel launch of a call
+    // (the same for header candidates and trigger lists, DTL_RX_ZERO_COPY_CANDS / _TRIG: measured, off -- one host read per
+    // SHORT workgroup is bound by the rate of small reads over the link: the header kernels took 2.25 instead of 1.0 ms)
+    bool zero_copy_cands_ = false, zero_copy_trig_ = false;
     bool zero_copy_descs_ = true;  // phase B reads the frame descriptors from pinned host memory (DTL_RX_ZERO_COPY_DESCS=0: copies)
     int flush_first_ = 2048, flush_frames_ = 8192; // phase B is handed over after this many frames of the demux walk (first / later hand-overs)
     int64_t split_min_ = int64_t(1) << 26; // calls with at least this many new samples run the sync stage in several ranges
