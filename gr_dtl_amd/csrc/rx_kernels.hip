@@ -12,7 +12,8 @@
 // std::complex<float> code on x86-64.
 #include "rx_kernels.h"
 #ifndef DTL_ABLATE
-#define DTL_ABLATE 0 // timing experiments only (tools/ablate.sh): 1 no derotation, 2 no butterflies, 3 no equaliser
+#define DTL_ABLATE 0 // timing experiments only (tools/ablate.sh): 1 no derotation, 2 no butterflies, 3 no equaliser;
+                     // demapper: 31 no exponentials, 32 no logarithms, 33 no stores, 34 no symbol loads
 #endif
 
 #include "dtl_math.h"
@@ -842,8 +843,13 @@ __device__ __forceinline__ void demap_log_ratios(const float (&p1)[BPS], const f
 #pragma unroll
         for (int j = 0; j < BPS; j++) least = fminf(least, fminf(p1[j], p0[j]));
         if (__all(least >= 1.17549435e-38f)) {
+#if DTL_ABLATE == 32
+#pragma unroll
+            for (int j = 0; j < BPS; j++) o[j] = p1[j] - p0[j];
+#else
 #pragma unroll
             for (int j = 0; j < BPS; j++) o[j] = dm_log<true>(p1[j]) - dm_log<true>(p0[j]);
+#endif
             return;
         }
     }
@@ -934,7 +940,12 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
             dm_f2 dist2[K], d[K];
 #pragma unroll
             for (int i = 0; i < K; i++) dist2[i] = dm_f2{ distance(m0 + 2 * i), distance(m0 + 2 * i + 1) };
+#if DTL_ABLATE == 31
+#pragma unroll
+            for (int i = 0; i < K; i++) d[i] = dist2[i] * dm_f2{ rinv, rinv };
+#else
             dm_exp_neg_div_by_pairs<K>(dist2, npwr, rinv, d);
+#endif
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 const int m = m0 + 2 * i;
@@ -1400,7 +1411,11 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     const cf32* pts = t.cnst_pts + cnst * 16;
     const float npwr = float(sqrt(stats[f].noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
     const float rinv = float(1.0 / double(npwr));        // the correctly rounded single reciprocal
+#if DTL_ABLATE == 34
+    const cf32 s = { 0.3f + 1e-3f * float(q & 63), -0.9f + 1e-3f * float(threadIdx.x & 31) };
+#else
     const cf32 s = soft_syms[size_t(f) * t.frame_capacity + q];
+#endif
     const uint32_t base = frames[f].llr_off;
     float* dst = llr_out + size_t(base) + size_t(q) * bps;
     float o[4];
@@ -1424,6 +1439,9 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     default:
         if (ord) soft_demap_symbol<4, MODE, true>(s, pts, npwr, rinv, o);
         else soft_demap_symbol<4, MODE>(s, pts, npwr, rinv, o);
+#if DTL_ABLATE == 33
+        if (o[0] + o[1] + o[2] + o[3] != 12345.678f) break;
+#endif
         if ((base & 3u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
         break;

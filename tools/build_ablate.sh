@@ -3,6 +3,7 @@
 # compiled -DDTL_ABLATE=<k> (results are wrong by construction; only kernel times mean something).
 #   1 / 2 / 3   frame equaliser without derotation / butterflies / equaliser (tools/ablate.sh)
 #   11 / 12     sync kernel without its window test / without strip totals either (tools/ablate_sync.sh)
+#   31 - 34     demapper without exponentials / logarithms / stores / symbol loads (tools/ablate.sh)
 # Run here (hipcc cross-compiles), then tools/ablate.sh or tools/ablate_sync.sh on the GPU box.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../gr_dtl_amd/csrc" && pwd)"
