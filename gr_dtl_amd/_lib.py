@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DTL_HIP_LIB") or os.path.join(_HERE, "libdtl_hip.so")  # override: a host-sanitizer build
 
 OK = 0
-ERR_INVALID_ARG, ERR_IO, ERR_HIP, ERR_TAGS_MISSING, ERR_CAPACITY, ERR_NO_DEVICE, ERR_UNSUPPORTED = (
-    -1, -2, -3, -4, -5, -6, -7)
+ERR_INVALID_ARG, ERR_IO, ERR_HIP, ERR_TAGS_MISSING, ERR_CAPACITY, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_INTERNAL = (
+    -1, -2, -3, -4, -5, -6, -7, -8)
 
 
 class DtlError(RuntimeError):

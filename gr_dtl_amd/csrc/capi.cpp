@@ -10,17 +10,63 @@
 #include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <sstream>
+#include <stdexcept>
+#include <system_error>
 
 namespace dtl {
 namespace {
-thread_local std::string g_last_error;
+thread_local char g_last_error[1024] = "";
 }
-void set_last_error(const std::string& msg) { g_last_error = msg; }
-const char* last_error() { return g_last_error.c_str(); }
+void set_last_error(const char* msg) noexcept
+{
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s", msg ? msg : "");
+}
+void set_last_error(const std::string& msg) noexcept { set_last_error(msg.c_str()); }
+const char* last_error() noexcept { return g_last_error; }
+
+namespace {
+// Every extern "C" entry point runs its body through this: no C++ exception leaves the library (the caller may be C, a
+// ctypes binding or a GNU Radio scheduler thread -- an exception there is std::terminate in the caller's process).
+// The reference throws out of work() instead (lib/dtl/ofdm_adaptive_frame_equalizer_vcvc_impl.cc:148-150,
+// lib/dtl/tb_decoder.cc:58-60); here those conditions are status codes, and what is caught below is the C++ runtime's own
+// failures: host memory (std::vector / std::string growth), a thread that cannot be started.
+template <typename F>
+int guarded(const char* who, F&& body) noexcept
+{
+    char text[960];
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        std::snprintf(text, sizeof(text), "%s: out of host memory (std::bad_alloc)", who);
+        set_last_error(text);
+        return DTL_ERR_CAPACITY;
+    } catch (const std::length_error& e) {
+        std::snprintf(text, sizeof(text), "%s: size beyond what a host container can hold (%s)", who, e.what());
+        set_last_error(text);
+        return DTL_ERR_CAPACITY;
+    } catch (const std::system_error& e) {
+        std::snprintf(text, sizeof(text), "%s: system error (%s)", who, e.what());
+        set_last_error(text);
+        return DTL_ERR_HIP;
+    } catch (const std::exception& e) {
+        std::snprintf(text, sizeof(text), "%s: unexpected exception (%s)", who, e.what());
+        set_last_error(text);
+        return DTL_ERR_INTERNAL;
+    } catch (...) {
+        std::snprintf(text, sizeof(text), "%s: unexpected exception", who);
+        set_last_error(text);
+        return DTL_ERR_INTERNAL;
+    }
+}
+} // namespace
 } // namespace dtl
+
+#define DTL_API_BEGIN(who) return ::dtl::guarded(who, [&]() -> int {
+#define DTL_API_END });
 
 struct dtl_ldpc {
     dtl::LdpcDecoder dec;
@@ -49,30 +95,34 @@ const char* dtl_version(void) { return "dtl-mi355x 0.1 (gfx950)"; }
 
 int dtl_device_count(void)
 {
+    DTL_API_BEGIN("dtl_device_count")
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+    DTL_API_END
 }
 
 int dtl_ldpc_create_from_text(const char* text, size_t len, int max_iterations, float sigma,
                               dtl_ldpc** out)
 {
+    DTL_API_BEGIN("dtl_ldpc_create_from_text")
     if (!text || !out) { dtl::set_last_error("ldpc_create: null argument"); return DTL_ERR_INVALID_ARG; }
     *out = nullptr;
-    auto* h = new (std::nothrow) dtl_ldpc();
-    if (!h) return DTL_ERR_CAPACITY;
+    auto h = std::make_unique<dtl_ldpc>();    // (owned until the handle is complete: an exception below must not leak it)
     std::string err = h->dec.code.parse_alist(std::string(text, len));
-    if (!err.empty()) { dtl::set_last_error(err); delete h; return DTL_ERR_INVALID_ARG; }
+    if (!err.empty()) { dtl::set_last_error(err); return DTL_ERR_INVALID_ARG; }
     h->dec.code.reduce();
     h->dec.code.build_schedules();
     if (max_iterations > 0) h->dec.max_iterations = max_iterations;
     if (sigma > 0) h->dec.sigma = sigma;
-    *out = h;
+    *out = h.release();
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_ldpc_create(const char* path, int max_iterations, float sigma, dtl_ldpc** out)
 {
+    DTL_API_BEGIN("dtl_ldpc_create")
     if (!path || !out) { dtl::set_last_error("ldpc_create: null argument"); return DTL_ERR_INVALID_ARG; }
     std::ifstream f(path);
     if (!f) { dtl::set_last_error(std::string("cannot open alist ") + path); return DTL_ERR_IO; }
@@ -80,39 +130,48 @@ int dtl_ldpc_create(const char* path, int max_iterations, float sigma, dtl_ldpc*
     ss << f.rdbuf();
     std::string text = ss.str();
     return dtl_ldpc_create_from_text(text.data(), text.size(), max_iterations, sigma, out);
+    DTL_API_END
 }
 
 void dtl_ldpc_destroy(dtl_ldpc* h) { delete h; }
 
 int dtl_ldpc_set_arith(dtl_ldpc* h, int32_t arith)
 {
+    DTL_API_BEGIN("dtl_ldpc_set_arith")
     if (!h || (arith != DTL_ARITH_GR_EXACT && arith != DTL_ARITH_FAST)) { dtl::set_last_error("ldpc_set_arith: bad argument"); return DTL_ERR_INVALID_ARG; }
     h->dec.arith = arith;
     return DTL_OK;
+    DTL_API_END
 }
 int dtl_ldpc_get_n(const dtl_ldpc* h) { return h ? h->dec.code.n : DTL_ERR_INVALID_ARG; }
 int dtl_ldpc_get_k(const dtl_ldpc* h) { return h ? h->dec.code.k : DTL_ERR_INVALID_ARG; }
 
 int dtl_ldpc_get_permute(const dtl_ldpc* h, int32_t* out)
 {
+    DTL_API_BEGIN("dtl_ldpc_get_permute")
     if (!h || !out) return DTL_ERR_INVALID_ARG;
     for (int i = 0; i < h->dec.code.n; i++) out[i] = h->dec.code.permute[i];
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_ldpc_encode_host(const dtl_ldpc* h, const uint8_t* data, uint8_t* out)
 {
+    DTL_API_BEGIN("dtl_ldpc_encode_host")
     if (!h || !data || !out) return DTL_ERR_INVALID_ARG;
     h->dec.code.encode(data, out);
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_ldpc_encode_batch_host(const dtl_ldpc* h, const uint8_t* data, size_t ncw, uint8_t* out)
 {
+    DTL_API_BEGIN("dtl_ldpc_encode_batch_host")
     if (!h || !data || !out) return DTL_ERR_INVALID_ARG;
     const int n = h->dec.code.n, k = h->dec.code.k;
     for (size_t i = 0; i < ncw; i++) h->dec.code.encode(data + i * k, out + i * n);
     return DTL_OK;
+    DTL_API_END
 }
 
 // device tables are created lazily so that creating/inspecting a code needs no GPU
@@ -130,6 +189,7 @@ static int ensure_uploaded(const dtl_ldpc* h)
 int dtl_ldpc_decode_gather(const dtl_ldpc* h, const float* d_llr, const dtl_cw_desc* d_desc,
                            size_t ncw, uint8_t* d_bits, int32_t* d_nit, void* stream)
 {
+    DTL_API_BEGIN("dtl_ldpc_decode_gather")
     if (!h) { dtl::set_last_error("ldpc_decode: null handle"); return DTL_ERR_INVALID_ARG; }
     if (!h->dec.uploaded()) {
         int rc = ensure_uploaded(h);
@@ -137,12 +197,15 @@ int dtl_ldpc_decode_gather(const dtl_ldpc* h, const float* d_llr, const dtl_cw_d
     }
     return h->dec.decode(d_llr, reinterpret_cast<const dtl::CwDesc*>(d_desc), ncw, d_bits, d_nit,
                          static_cast<hipStream_t>(stream));
+    DTL_API_END
 }
 
 int dtl_ldpc_decode_batch(const dtl_ldpc* h, const float* d_llr, size_t ncw, uint8_t* d_bits,
                           int32_t* d_nit, void* stream)
 {
+    DTL_API_BEGIN("dtl_ldpc_decode_batch")
     return dtl_ldpc_decode_gather(h, d_llr, nullptr, ncw, d_bits, d_nit, stream);
+    DTL_API_END
 }
 
 
@@ -175,59 +238,68 @@ static int fill_config(const dtl_rx_cfg* c, dtl::RxConfig& g, const char* who)
     g.initial_mcs = c->initial_mcs; g.hysteresis = c->hysteresis; g.decision_th = c->decision_th > 0 ? c->decision_th : 5;
     if (c->arith != DTL_ARITH_GR_EXACT && c->arith != DTL_ARITH_FAST) { dtl::set_last_error(std::string(who) + ": arith must be DTL_ARITH_GR_EXACT or DTL_ARITH_FAST"); return DTL_ERR_INVALID_ARG; }
     g.arith = c->arith;
+    if (c->device < -1) { dtl::set_last_error(std::string(who) + ": device must be a HIP device index or DTL_DEVICE_CURRENT"); return DTL_ERR_INVALID_ARG; }
+    g.device = c->device;
     return DTL_OK;
 }
 
 int dtl_rx_create(const dtl_rx_cfg* c, dtl_rx** out)
 {
+    DTL_API_BEGIN("dtl_rx_create")
     if (!c || !out) { dtl::set_last_error("rx_create: null argument"); return DTL_ERR_INVALID_ARG; }
     *out = nullptr;
-    auto* h = new (std::nothrow) dtl_rx();
-    if (!h) return DTL_ERR_CAPACITY;
+    auto h = std::make_unique<dtl_rx>();
     int rc = fill_config(c, h->rx.cfg, "rx_create");
     if (rc == DTL_OK) rc = h->rx.init();
-    if (rc != DTL_OK) { delete h; return rc; }
-    *out = h;
+    if (rc != DTL_OK) return rc;
+    *out = h.release();
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_tx_create(const dtl_rx_cfg* c, dtl_tx** out)
 {
+    DTL_API_BEGIN("dtl_tx_create")
     if (!c || !out) { dtl::set_last_error("tx_create: null argument"); return DTL_ERR_INVALID_ARG; }
     *out = nullptr;
-    auto* h = new (std::nothrow) dtl_tx();
-    if (!h) return DTL_ERR_CAPACITY;
+    auto h = std::make_unique<dtl_tx>();
     int rc = fill_config(c, h->tx.cfg, "tx_create");
     if (rc == DTL_OK) rc = h->tx.init();
-    if (rc != DTL_OK) { delete h; return rc; }
-    *out = h;
+    if (rc != DTL_OK) return rc;
+    *out = h.release();
     return DTL_OK;
+    DTL_API_END
 }
 
 void dtl_tx_destroy(dtl_tx* h) { delete h; }
 
 int dtl_constellation_points_host(int32_t constellation, float* points16, int32_t* n_points)
 {
+    DTL_API_BEGIN("dtl_constellation_points_host")
     if (!points16 || !n_points || constellation < 1 || constellation > 4) { dtl::set_last_error("Unknown constellation"); return DTL_ERR_INVALID_ARG; }
     dtl::cf32 p[16];
     dtl::constellation_points_host(constellation, p);
     std::memcpy(points16, p, sizeof(p));
     *n_points = 1 << constellation;
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_header_format_host(const dtl_tx_frame_info* fields, int32_t has_fec, int32_t header_len_bits, uint8_t* bits_out)
 {
+    DTL_API_BEGIN("dtl_header_format_host")
     if (!fields || !bits_out || header_len_bits < 16) { dtl::set_last_error("header_format: bad argument"); return DTL_ERR_INVALID_ARG; }
     dtl::TxFrameInfo f;
     std::memcpy(&f, fields, sizeof(f));
     dtl::format_header_bits(f, has_fec != 0, header_len_bits, bits_out);
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_tx_plan(dtl_tx* h, int64_t n_user, int32_t constellation, int32_t fec, int32_t first_frame_no,
                 int32_t first_tb_no, dtl_tx_frame_info* frames_out, int64_t cap, int64_t* n_out)
 {
+    DTL_API_BEGIN("dtl_tx_plan")
     if (!h || !n_out || n_user < 0 || cap < 0 || (cap && !frames_out)) { dtl::set_last_error("tx_plan: bad argument"); return DTL_ERR_INVALID_ARG; }
     int rc = h->tx.plan(n_user, constellation, fec, first_frame_no, first_tb_no);
     if (rc != DTL_OK) return rc;
@@ -235,12 +307,14 @@ int dtl_tx_plan(dtl_tx* h, int64_t n_user, int32_t constellation, int32_t fec, i
     if (*n_out > cap) { dtl::set_last_error("tx_plan: frame capacity too small"); return DTL_ERR_CAPACITY; }
     std::memcpy(frames_out, h->tx.frames.data(), h->tx.frames.size() * sizeof(dtl_tx_frame_info));
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t constellation, int32_t fec,
                    int32_t first_frame_no, int32_t first_tb_no, int32_t gap, int32_t want_syms, void* stream,
                    dtl_tx_result* out)
 {
+    DTL_API_BEGIN("dtl_tx_process")
     if (!h || !out) { dtl::set_last_error("tx_process: null argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
     dtl::Transmitter& t = h->tx;
@@ -259,6 +333,7 @@ int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t con
     out->hdr_bits = t.hdr_bits();
     out->frame_samples = t.frame_samples();
     return DTL_OK;
+    DTL_API_END
 }
 
 void dtl_rx_destroy(dtl_rx* h) { delete h; }
@@ -297,20 +372,24 @@ static int rx_run(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, int m
     out->d_cw_nit = r.d_cw_nit.as<int32_t>();
     for (int i = 0; i < 8; i++) out->stage_ms[i] = r.stage_ms[i];
     out->frame_capacity = r.frame_capacity();
-    out->hdr_bits = r.cfg.header_len() * int(r.cfg.occupied_carriers[0].size());
+    out->hdr_bits = r.hdr_bits();            // the row stride of d_hdr_bits (RxTables.hdr_bits)
     out->frame_samples = r.frame_samples();
     return DTL_OK;
 }
 
 int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void* stream, dtl_rx_result* out)
 {
+    DTL_API_BEGIN("dtl_rx_process")
     return rx_run(h, d_iq, n, flags, -1, stream, out);
+    DTL_API_END
 }
 
 int dtl_rx_process_stream(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, int32_t final, void* stream,
                           dtl_rx_result* out)
 {
+    DTL_API_BEGIN("dtl_rx_process_stream")
     return rx_run(h, d_iq, n, flags, final ? 1 : 0, stream, out);
+    DTL_API_END
 }
 
 void dtl_rx_reset(dtl_rx* h) { if (h) h->rx.reset_stream(); }
@@ -319,13 +398,16 @@ int64_t dtl_rx_stream_position(const dtl_rx* h) { return h ? h->rx.stream_positi
 
 int dtl_rx_kernel_ms(dtl_rx* h, int32_t back, double* ldpc_ms, double* payload_ms)
 {
+    DTL_API_BEGIN("dtl_rx_kernel_ms")
     if (!h) { dtl::set_last_error("rx_kernel_ms: null handle"); return DTL_ERR_INVALID_ARG; }
     return h->rx.kernel_times(back, ldpc_ms, payload_ms);
+    DTL_API_END
 }
 
 int dtl_sync_sc(const float* d_iq, int64_t n, int32_t fft_len, int32_t cp_len, float threshold, float* d_metric,
                 int64_t* triggers_host, float* angles_host, int64_t cap, int64_t* n_out, void* stream)
 {
+    DTL_API_BEGIN("dtl_sync_sc")
     if (!n_out || n < 0 || (n && !d_iq) || cap < 0 || (cap && (!triggers_host || !angles_host))) {
         dtl::set_last_error("sync_sc: bad argument");
         return DTL_ERR_INVALID_ARG;
@@ -365,27 +447,33 @@ int dtl_sync_sc(const float* d_iq, int64_t n, int32_t fft_len, int32_t cp_len, f
     DTL_HIP_CHECK(hipStreamSynchronize(st));
     std::copy(trig.begin(), trig.end(), triggers_host);
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_fft_batch(const float* d_in, float* d_out, int64_t n_vectors, int32_t fft_len, int32_t forward, void* stream)
 {
+    DTL_API_BEGIN("dtl_fft_batch")
     if (n_vectors < 0 || (n_vectors && (!d_in || !d_out))) { dtl::set_last_error("fft_batch: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
     return dtl::launch_fft_batch(reinterpret_cast<const dtl::cf32*>(d_in), reinterpret_cast<dtl::cf32*>(d_out), n_vectors,
                                  fft_len, forward, static_cast<hipStream_t>(stream));
+    DTL_API_END
 }
 
 int dtl_soft_demap(const float* d_syms, int64_t n_syms, int32_t constellation, double noise, int32_t dist_mode,
                    float* d_llr, void* stream)
 {
+    DTL_API_BEGIN("dtl_soft_demap")
     if (n_syms < 0 || (n_syms && (!d_syms || !d_llr))) { dtl::set_last_error("soft_demap: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
     return dtl::launch_soft_demap(reinterpret_cast<const dtl::cf32*>(d_syms), n_syms, constellation, noise, dist_mode, d_llr,
                                   static_cast<hipStream_t>(stream));
+    DTL_API_END
 }
 
 int dtl_crc32(const uint8_t* d_bytes, int64_t len, uint32_t* crc_host, void* stream)
 {
+    DTL_API_BEGIN("dtl_crc32")
     if (!crc_host || len < 0 || (len && !d_bytes)) { dtl::set_last_error("crc32: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
     auto* st = static_cast<hipStream_t>(stream);
@@ -397,29 +485,35 @@ int dtl_crc32(const uint8_t* d_bytes, int64_t len, uint32_t* crc_host, void* str
     DTL_HIP_CHECK(hipMemcpyAsync(crc_host, d_out.p, 4, hipMemcpyDeviceToHost, st));
     DTL_HIP_CHECK(hipStreamSynchronize(st));
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_chanest(dtl_rx* h, const float* d_sync_syms, int64_t n, int32_t* d_carr_offset, float* d_taps, void* stream)
 {
+    DTL_API_BEGIN("dtl_chanest")
     if (!h || n < 0 || n > 0x7fffffff) { dtl::set_last_error("chanest: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
     return h->rx.chanest(reinterpret_cast<const dtl::cf32*>(d_sync_syms), int(n), d_carr_offset,
                          reinterpret_cast<dtl::cf32*>(d_taps), static_cast<hipStream_t>(stream));
+    DTL_API_END
 }
 
 int dtl_header_decode(dtl_rx* h, const float* d_hdr_syms, const float* d_taps, const int32_t* d_carr_offset, int64_t n,
                       dtl_header_fields* fields_host, uint8_t* d_hdr_bits, float* d_taps_out, void* stream)
 {
+    DTL_API_BEGIN("dtl_header_decode")
     if (!h || n < 0 || n > 0x7fffffff) { dtl::set_last_error("header_decode: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
     return h->rx.header_decode(reinterpret_cast<const dtl::cf32*>(d_hdr_syms), reinterpret_cast<const dtl::cf32*>(d_taps),
                                d_carr_offset, int(n), reinterpret_cast<dtl::HeaderRec*>(fields_host), d_hdr_bits,
                                reinterpret_cast<dtl::cf32*>(d_taps_out), static_cast<hipStream_t>(stream));
+    DTL_API_END
 }
 
 int dtl_equalize_frames(dtl_rx* h, const float* d_frames, const float* d_taps, const dtl_frame_eq_in* in_host, int64_t n,
                         float* d_eq_hard, float* d_eq_soft, float* d_soft_syms, dtl_frame_eq_out* out_host, void* stream)
 {
+    DTL_API_BEGIN("dtl_equalize_frames")
     if (!h || n < 0 || n > 0x7fffffff || (n > 0 && !in_host)) { dtl::set_last_error("equalize_frames: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device"); return DTL_ERR_NO_DEVICE; }
     std::vector<dtl::FrameDesc> descs(static_cast<size_t>(n));
@@ -433,12 +527,14 @@ int dtl_equalize_frames(dtl_rx* h, const float* d_frames, const float* d_taps, c
                                  descs.data(), int(n), reinterpret_cast<dtl::cf32*>(d_eq_hard),
                                  reinterpret_cast<dtl::cf32*>(d_eq_soft), reinterpret_cast<dtl::cf32*>(d_soft_syms),
                                  reinterpret_cast<dtl::FrameStat*>(out_host), static_cast<hipStream_t>(stream));
+    DTL_API_END
 }
 
 int dtl_tb_gather(const int32_t* code_n, const int32_t* code_k, int32_t n_codes, int32_t frame_capacity, int32_t max_bps,
                   const dtl_rx_frame_info* frames_host, int64_t n_frames, dtl_cw_desc* d_cw_desc, int64_t cw_cap,
                   int64_t* n_cw, dtl_tb_span* spans_host, int64_t span_cap, int64_t* n_spans, void* stream)
 {
+    DTL_API_BEGIN("dtl_tb_gather")
     if (!code_n || !code_k || n_codes <= 0 || frame_capacity <= 0 || max_bps < 1 || max_bps > 4 || n_frames < 0 ||
         (n_frames > 0 && !frames_host) || !n_cw || !n_spans) {
         dtl::set_last_error("tb_gather: bad argument");
@@ -470,19 +566,23 @@ int dtl_tb_gather(const int32_t* code_n, const int32_t* code_k, int32_t n_codes,
     if (rc != DTL_OK) return rc;
     DTL_HIP_CHECK(hipStreamSynchronize(st));
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_copy_device(void* dst, const void* src, size_t bytes, void* stream)
 {
+    DTL_API_BEGIN("dtl_copy_device")
     if (!bytes) return DTL_OK;
     if (!dst || !src) return DTL_ERR_INVALID_ARG;
     DTL_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, int64_t stream_len,
                  int64_t* out, int64_t out_cap, int64_t* n_out)
 {
+    DTL_API_BEGIN("dtl_fix_sync")
     if (!n_out || (n_triggers && !triggers)) return DTL_ERR_INVALID_ARG;
     dtl::FrameDetectState st;
     st.frame_len = frame_len;
@@ -491,10 +591,12 @@ int dtl_fix_sync(int32_t frame_len, const int64_t* triggers, int64_t n_triggers,
     if (int64_t(res.size()) > out_cap) return DTL_ERR_CAPACITY;
     std::copy(res.begin(), res.end(), out);
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_sync_pretest_check(const float* d_iq, int64_t n, int32_t fft_len, float threshold, uint64_t* counts_host, void* stream)
 {
+    DTL_API_BEGIN("dtl_sync_pretest_check")
     if (!counts_host || n < 0 || (n && !d_iq)) { dtl::set_last_error("sync_pretest_check: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
     counts_host[0] = counts_host[1] = counts_host[2] = 0;
@@ -517,12 +619,14 @@ int dtl_sync_pretest_check(const float* d_iq, int64_t n, int32_t fft_len, float 
     DTL_HIP_CHECK(hipStreamSynchronize(st));
     for (int i = 0; i < 3; i++) counts_host[i] = uint64_t(c[i]);
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_fix_sync_chunked(int32_t frame_len, const int64_t* triggers, int64_t n_triggers, const int64_t* buf_ends,
                          int64_t n_bufs, const int64_t* horizons, int64_t n_horizons, int64_t* out, int64_t out_cap,
                          int64_t* n_out)
 {
+    DTL_API_BEGIN("dtl_fix_sync_chunked")
     if (!n_out || (n_triggers && !triggers) || (n_bufs && !buf_ends) || (n_horizons && !horizons)) return DTL_ERR_INVALID_ARG;
     dtl::FrameDetectState st;
     st.frame_len = frame_len;
@@ -549,11 +653,13 @@ int dtl_fix_sync_chunked(int32_t frame_len, const int64_t* triggers, int64_t n_t
     if (int64_t(res.size()) > out_cap) return DTL_ERR_CAPACITY;
     std::copy(res.begin(), res.end(), out);
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_plateau_detect(const float* metric, int64_t n, float thr, int32_t max_len, int64_t* out, int64_t out_cap,
                        int64_t* n_out)
 {
+    DTL_API_BEGIN("dtl_plateau_detect")
     if (!metric || !n_out) return DTL_ERR_INVALID_ARG;
     std::vector<unsigned long long> edges;
     bool prev = false;
@@ -567,12 +673,14 @@ int dtl_plateau_detect(const float* metric, int64_t n, float thr, int32_t max_le
     if (int64_t(res.size()) > out_cap) return DTL_ERR_CAPACITY;
     std::copy(res.begin(), res.end(), out);
     return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_feedback_sequence(int32_t n_mcs, const double* mcs_snr, const int32_t* mcs_cnst, const int32_t* mcs_fec,
                           double hysteresis, int32_t decision_th, int32_t initial_mcs, const double* snr, int64_t n,
                           int32_t* out_cnst, int32_t* out_fec)
 {
+    DTL_API_BEGIN("dtl_feedback_sequence")
     if (n_mcs <= 0 || !mcs_snr || !mcs_cnst || !mcs_fec || !snr || !out_cnst || !out_fec) return DTL_ERR_INVALID_ARG;
     std::vector<dtl::McsEntry> lut;
     for (int i = 0; i < n_mcs; i++) lut.push_back({ mcs_snr[i], mcs_cnst[i], mcs_fec[i] });
@@ -580,6 +688,7 @@ int dtl_feedback_sequence(int32_t n_mcs, const double* mcs_snr, const int32_t* m
     fb.init(lut, hysteresis, decision_th, initial_mcs);
     for (int64_t i = 0; i < n; i++) fb.get(snr[i], &out_cnst[i], &out_fec[i]);
     return DTL_OK;
+    DTL_API_END
 }
 
 } // extern "C"

@@ -12,8 +12,11 @@
 
 namespace dtl {
 
-void set_last_error(const std::string& msg);
-const char* last_error();
+// The error text of the calling thread lives in a fixed thread-local buffer: setting it never allocates and never
+// throws, so it can be called from a catch handler for std::bad_alloc.
+void set_last_error(const char* msg) noexcept;
+void set_last_error(const std::string& msg) noexcept;
+const char* last_error() noexcept;
 
 struct HipError {
     hipError_t e;

@@ -21,7 +21,11 @@
 #include <condition_variable>
 #include <initializer_list>
 #include <limits>
+#include <atomic>
+#include <functional>
 #include <mutex>
+#include <stdexcept>
+#include <system_error>
 #include <thread>
 
 namespace dtl {
@@ -65,6 +69,37 @@ int HostBuf::ensure(size_t bytes)
 static int device_view(const HostBuf& hb, void** out)
 {
     DTL_HIP_CHECK(hipHostGetDevicePointer(out, hb.p, 0));
+    return DTL_OK;
+}
+
+int DeviceScope::enter(int device)
+{
+    if (device < 0) return DTL_OK;
+    int cur = -1;
+    DTL_HIP_CHECK(hipGetDevice(&cur));
+    if (cur == device) return DTL_OK;
+    DTL_HIP_CHECK(hipSetDevice(device));
+    prev = cur;
+    switched = true;
+    return DTL_OK;
+}
+
+DeviceScope::~DeviceScope()
+{
+    if (switched) (void)hipSetDevice(prev);
+}
+
+int RxConfig::check_header_plan() const
+{
+    if (occupied_carriers.empty()) return DTL_OK;   // (reported by the caller's own checks)
+    int sum = 0;
+    for (int i = 0; i < header_len(); i++) sum += int(occupied_carriers[size_t(i) % occupied_carriers.size()].size());
+    if (sum != header_bits()) {
+        set_last_error("occupied_carriers: the carrier sets of the header symbols hold " + std::to_string(sum) + " bits, the header "
+                       "formatter (header_len x len(occupied_carriers[0]), python/dtl/ofdm_receiver.py:129-130) " +
+                       std::to_string(header_bits()) + ": the reference's header parser and demux would fall out of step");
+        return DTL_ERR_INVALID_ARG;
+    }
     return DTL_OK;
 }
 
@@ -529,6 +564,54 @@ struct Receiver::StreamState {
     long lost_total = 0;
 };
 
+// The sync stage's helper thread (stage_sync): ONE thread per receiver, started when the first call needs it and kept for
+// the handle's lifetime (a std::thread per call cost its creation and join inside every step, and its constructor can
+// throw std::system_error).  run() hands over a job, wait() returns when the job has finished; a job never lets an
+// exception out (it reports through its own result fields).
+class Receiver::Worker {
+public:
+    Worker() : th_([this] { loop(); }) {}
+    ~Worker()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    void run(std::function<void()> job)
+    {
+        { std::lock_guard<std::mutex> lk(mu_); job_ = std::move(job); has_job_ = true; done_ = false; }
+        cv_.notify_all();
+    }
+    void wait() noexcept
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return done_; });
+    }
+
+private:
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return quit_ || has_job_; });
+                if (quit_) return;
+                job = std::move(job_);
+                has_job_ = false;
+            }
+            try { job(); } catch (...) { /* jobs report through their own result fields */ }
+            { std::lock_guard<std::mutex> lk(mu_); done_ = true; }
+            cv_done_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, cv_done_;
+    std::function<void()> job_;
+    bool has_job_ = false, done_ = true, quit_ = false;
+    std::thread th_;    // last member: the thread starts when everything it touches exists
+};
+
 Receiver::Receiver() : ss_(std::make_unique<StreamState>())
 {
     // tests lower the threshold so that small streams take the pipelined (four ranges, early header launches) path
@@ -541,13 +624,11 @@ Receiver::Receiver() : ss_(std::make_unique<StreamState>())
     if (const char* e = getenv("DTL_RX_FLUSH_FIRST")) flush_first_ = std::max(64, atoi(e));
 }
 
-void Receiver::reset_stream()
+void Receiver::reset_stream() noexcept
 {
-    const double t_a = now_ms();
     if (side_) (void)hipStreamSynchronize(side_); // a failed call may leave trigger-angle work in flight
-    const double t_b = now_ms();
-    ss_ = std::make_unique<StreamState>();
-    if (getenv("DTL_DEBUG")) fprintf(stderr, "  [reset_stream: side stream %.3f ms, state %.3f ms]\n", t_b - t_a, now_ms() - t_b);
+    // in place (no allocation: this runs from destructors while an exception unwinds the failed call)
+    *ss_ = StreamState{};
 }
 
 int64_t Receiver::stream_position() const { return ss_->next_abs; }
@@ -603,6 +684,7 @@ int Receiver::init()
     for (auto& set : cfg.pilot_symbols)
         if (set.size() != np) { set_last_error("pilot symbol sets must match the pilot carriers"); return DTL_ERR_INVALID_ARG; }
     if (!cfg.pilot_carriers.empty() && cfg.pilot_symbols.empty()) { set_last_error("pilot_symbols empty"); return DTL_ERR_INVALID_ARG; }
+    DTL_TRY(cfg.check_header_plan());
     capacity_ = 0;
     for (int i = 0; i < cfg.frame_length; i++) capacity_ += int(cfg.occupied_carriers[i % cfg.occupied_carriers.size()].size());
     decoders_.clear();
@@ -757,8 +839,7 @@ int Receiver::upload_tables()
     tab_.has_fec = cfg.has_fec ? 1 : 0;
     tab_.n_occ_sets = n_occ_sets; tab_.max_occ = max_occ; tab_.n_pilot_sets = n_pilot_sets; tab_.n_pilots = n_pilots;
     tab_.n_pilot_sym_sets = n_psym; tab_.frame_capacity = capacity_;
-    tab_.hdr_bits = 0;
-    for (int i = 0; i < h; i++) tab_.hdr_bits += occ_len[i % n_occ_sets];
+    tab_.hdr_bits = cfg.header_bits();   // == the sum over the header symbols' carrier sets (check_header_plan, init())
     tab_.g_min = gmin; tab_.g_max = gmax;
     tab_.eq_alpha = cfg.eq_alpha; tab_.llr_dist_mode = (cfg.llr_dist_mode & 0x1ff) | (cfg.arith == DTL_ARITH_FAST ? DTL_DEMAP_FAST : 0);
     tab_.twiddle = reinterpret_cast<const cf32*>(b + o_tw);
@@ -995,8 +1076,9 @@ int Receiver::stage_sync(Call& c)
             // header kernel.  One thread doing both needs ~0.55 ms per 16 k triggers against 0.34 ms of sync kernel: the
             // device would wait for the host.  With several ranges X runs on a helper thread (it touches the detector's
             // carry state and the pinned edge buffer only; HIP calls: event wait, the rare overflow copy), Y here.
-            struct RangeOut { std::vector<int64_t> trig; int64_t produced = 0; unsigned n_edges = 0; int rc = DTL_OK; double ms = 0; bool ready = false; std::string err; };
+            struct RangeOut { std::vector<int64_t> trig; int64_t produced = 0; unsigned n_edges = 0; int rc = DTL_OK; double ms = 0; bool ready = false; char err[200] = ""; };
             std::vector<RangeOut> outs(rg.size());
+            std::atomic<bool> fix_failed{ false };
             std::mutex mu;
             std::condition_variable cv;
             int dev = 0;
@@ -1035,33 +1117,73 @@ int Receiver::stage_sync(Call& c)
                 ss.fds.frame_len = (L + hdr_syms) * P; // ofdm_receiver.py:77-78
                 c_.fix = std::make_unique<FixSyncRun>(ss.fds);
             }
-            std::thread helper;
-            struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ helper };
-            if (rg.size() > 1) {
-                helper = std::thread([&]() {
-                    (void)hipSetDevice(dev);                      // a new thread starts on device 0
-                    bool failed = false;
-                    for (size_t c = 0; c < rg.size(); c++) {
-                        RangeOut& o = outs[c];
-                        if (!failed) { o.rc = stage_x(c, hoffs[c], o); failed = o.rc != DTL_OK; if (failed) o.err = last_error(); /* the error text is per thread */ }
-                        else o.rc = DTL_ERR_HIP;                  // (never reported: the caller stops at the failed range)
-                        { std::lock_guard<std::mutex> lk(mu); o.ready = true; }
-                        cv.notify_all();
-                        if (!failed) { const double t_f = now_ms(); feed_fix(o); o.ms += now_ms() - t_f; }
+            // Who touches what while the helper runs: the helper owns ss.edge_carry, ss.plateau_i, ss.fds (through c_.fix)
+            // and reads the pinned edge / counter buffers; this thread owns everything else of the stream state (ss.segs,
+            // the trigger lists, the candidate bookkeeping).  RangeOut entries cross over under `mu` (`ready`).
+            // `cancel`: set before this thread leaves the stage early (an error), so that the helper stops at the next range
+            // instead of walking all of them; the failed call's stream state is discarded anyway (process_stream resets it).
+            std::atomic<bool> cancel{ false };
+            auto helper_job = [&]() {
+                (void)hipSetDevice(dev);                          // (a new thread starts on device 0)
+                int fail_rc = DTL_OK;                             // != OK: this and every later range report it
+                const char* fail_text = "";
+                for (size_t c = 0; c < rg.size(); c++) {
+                    RangeOut& o = outs[c];
+                    if (fail_rc == DTL_OK && cancel.load(std::memory_order_acquire)) { fail_rc = DTL_ERR_HIP; fail_text = "sync stage: cancelled"; }
+                    if (fail_rc == DTL_OK) {
+                        try {
+                            o.rc = stage_x(c, hoffs[c], o);
+                            if (o.rc != DTL_OK) { fail_rc = o.rc; fail_text = last_error(); /* the error text is per thread */ }
+                        } catch (const std::bad_alloc&) {
+                            fail_rc = DTL_ERR_CAPACITY; fail_text = "sync stage: out of host memory";
+                        } catch (...) {
+                            fail_rc = DTL_ERR_INTERNAL; fail_text = "sync stage: unexpected exception";
+                        }
                     }
-                });
+                    if (fail_rc != DTL_OK) { o.rc = fail_rc; std::snprintf(o.err, sizeof(o.err), "%s", fail_text); }
+                    { std::lock_guard<std::mutex> lk(mu); o.ready = true; }
+                    cv.notify_all();
+                    if (fail_rc == DTL_OK && !cancel.load(std::memory_order_acquire)) {
+                        try {
+                            const double t_f = now_ms(); feed_fix(o); o.ms += now_ms() - t_f;
+                        } catch (...) {                           // the walk's vectors could not grow
+                            fail_rc = DTL_ERR_CAPACITY; fail_text = "frame_detect walk: out of host memory";
+                            fix_failed.store(true, std::memory_order_release);
+                        }
+                    }
+                }
+            };
+            bool helper_on = false;
+            if (rg.size() > 1 && !worker_failed_) {
+                // a helper that cannot be started (std::system_error from std::thread, std::bad_alloc) is no reason to fail
+                // the call: the stage then runs on this thread alone, and the handle does not try again
+                try {
+                    if (getenv("DTL_RX_FAIL_HELPER")) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "DTL_RX_FAIL_HELPER"); // (tests)
+                    if (!worker_) worker_ = std::make_unique<Worker>();
+                    worker_->run(helper_job);
+                    helper_on = true;
+                } catch (const std::exception&) {
+                    worker_failed_ = true;
+                    worker_.reset();
+                }
             }
+            // declared behind everything the helper's job refers to: destroyed first, i.e. the job has ended before any of it
+            // goes out of scope, whichever way this function is left
+            struct Joiner {
+                Worker* w; std::atomic<bool>& cancel;
+                ~Joiner() { if (w) { cancel.store(true, std::memory_order_release); w->wait(); } }
+            } joiner{ helper_on ? worker_.get() : nullptr, cancel };
             for (size_t c = 0; c < rg.size(); c++) {
                 const bool last = c + 1 == rg.size();
                 RangeOut& o = outs[c];
-                if (helper.joinable()) {
+                if (helper_on) {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return o.ready; });
                 } else {
                     o.rc = stage_x(c, hoffs[c], o);
                 }
                 lap("  range: crossings sorted, plateaus found");
-                if (o.rc != DTL_OK) { if (!o.err.empty()) set_last_error(o.err); return o.rc; }
+                if (o.rc != DTL_OK) { if (o.err[0]) set_last_error(o.err); return o.rc; }
                 const unsigned n_edges = o.n_edges;
                 std::vector<int64_t>& trig = o.trig;
                 produced = o.produced;
@@ -1077,7 +1199,7 @@ int Receiver::stage_sync(Call& c)
                 }
                 DTL_TRY(submit_angles(c_, first, trig.size(), side_));
                 lap("  range: submit angles");
-                if (!helper.joinable()) { feed_fix(o); lap("  range: frame_detect"); }  // (one range: everything on this thread)
+                if (!helper_on) { feed_fix(o); lap("  range: frame_detect"); }  // (no helper: everything on this thread)
                 // The oscillator segments of this range, then the headers of every trigger whose segments are complete
                 // and whose header symbols lie in front of `produced` (a later range decides what the others see):
                 // queued behind the sync kernels, they keep the device busy while the host deals with the next range
@@ -1090,7 +1212,8 @@ int Receiver::stage_sync(Call& c)
                 }
                 lap("  range: speculate headers");
             }
-            if (helper.joinable()) helper.join();
+            if (helper_on) worker_->wait();
+            if (fix_failed.load(std::memory_order_acquire)) { set_last_error("frame_detect walk: out of host memory"); return DTL_ERR_CAPACITY; }
             for (const auto& o : outs) plateau_ms += o.ms;
             lap("helper joined");
         } else {
@@ -1382,6 +1505,8 @@ static int check_block_inputs(const char* what, std::initializer_list<std::pair<
 int Receiver::chanest(const cf32* d_sync_syms, int n, int32_t* d_carr_off, cf32* d_taps, hipStream_t st)
 {
     if (n < 0 || (n > 0 && (!d_sync_syms || !d_carr_off || !d_taps))) { set_last_error("chanest: bad argument"); return DTL_ERR_INVALID_ARG; }
+    DeviceScope dev;
+    DTL_TRY(dev.enter(cfg.device));
     if (!uploaded_) DTL_TRY(upload_tables());
     DTL_TRY(check_block_inputs("chanest", { { d_sync_syms, size_t(n) * 2 * cfg.fft_len } }, st));
     HeaderStageIo io;
@@ -1395,6 +1520,8 @@ int Receiver::header_decode(const cf32* d_hdr_syms, const cf32* d_taps, const in
 {
     if (n < 0 || (n > 0 && (!d_hdr_syms || !d_taps || !d_carr_off || !recs_host))) { set_last_error("header_decode: bad argument"); return DTL_ERR_INVALID_ARG; }
     if (n == 0) return DTL_OK;
+    DeviceScope dev;
+    DTL_TRY(dev.enter(cfg.device));
     if (!uploaded_) DTL_TRY(upload_tables());
     DTL_TRY(check_block_inputs("header_decode", { { d_hdr_syms, size_t(n) * cfg.header_len() * cfg.fft_len }, { d_taps, size_t(n) * cfg.fft_len } }, st));
     DevBuf recs, taps_scratch;
@@ -1419,6 +1546,8 @@ int Receiver::equalize_frames(const cf32* d_frames, const cf32* d_taps, const Fr
             set_last_error("Missing constellation tag.");
             return DTL_ERR_TAGS_MISSING;
         }
+    DeviceScope dev;
+    DTL_TRY(dev.enter(cfg.device));
     if (!uploaded_) DTL_TRY(upload_tables());
     DTL_TRY(check_block_inputs("equalize_frames", { { d_frames, size_t(n) * cfg.frame_length * cfg.fft_len }, { d_taps, size_t(n) * cfg.fft_len } }, st));
     DevBuf descs, stats, syms_scratch;
@@ -1940,6 +2069,13 @@ int Receiver::stream_end(Call& c)
 }
 
 int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st)
+{
+    DeviceScope dev;                     // dtl_rx_cfg.device: current for this call, the caller's own afterwards
+    DTL_TRY(dev.enter(cfg.device));
+    return process_stream_body(d_iq, n, flags, final, st);
+}
+
+int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st)
 {
     StreamState& ss = *ss_;
     struct ResetOnExit { // a failed or final call ends the stream

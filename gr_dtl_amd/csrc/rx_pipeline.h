@@ -35,12 +35,29 @@ struct RxConfig {
     int max_iterations = 15;
     float bp_sigma = 0.0f; // 0 => sqrt(2)
     int arith = 0;         // DTL_ARITH_GR_EXACT / DTL_ARITH_FAST: decoder + 16-QAM demapper arithmetic
+    int device = -1;       // HIP device of the handle (dtl_rx_cfg.device); -1: the calling thread's current device
     std::vector<std::string> alist_texts; // fec_codes, index i -> FEC id i+1
     std::vector<McsEntry> mcs;
     int initial_mcs = 0;
     double hysteresis = 1.0;  // ofdm_receiver.py:167 ofdm_adaptive_feedback_decision(1, 5, ...)
     int decision_th = 5;
     int header_len() const { return has_fec ? 2 : 1; } // ofdm_receiver.py:66-68
+    // Bits of one packet header: the reference builds its formatter from occupied_carriers[0] alone, once per header symbol
+    // (python/dtl/ofdm_receiver.py:129-130, python/dtl/ofdm_transmitter.py:76-78)
+    int header_bits() const { return header_len() * int(occupied_carriers.empty() ? 0 : occupied_carriers[0].size()); }
+    // -> DTL_OK, or DTL_ERR_INVALID_ARG when the header symbols' own carrier sets (symbol i uses set i mod n_sets in the
+    // serializer / carrier allocator) do not hold exactly header_bits(): packet_headerparser_b consumes header_bits() items
+    // per header while ofdm_serializer_vcc delivers the sets' sum per frame -- parser and demux would fall out of step in
+    // the reference; here such a plan is refused when the handle is created
+    int check_header_plan() const;
+};
+
+// makes the handle's device current for the duration of a call and restores the caller's afterwards
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device);   // device < 0: nothing to do
+    ~DeviceScope();
 };
 
 // lib/dtl/ofdm_adaptive_frame_detect_bb_impl.cc state (d_* members)
@@ -146,7 +163,7 @@ public:
     // frames that are not complete yet are carried to the next call; `final` flushes the stream the
     // way process() treats the end of its batch and resets the state.
     int process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream);
-    void reset_stream();
+    void reset_stream() noexcept;
     int64_t stream_position() const; // samples consumed since the last reset
     // device time of the phase-B kernels and of the LDPC kernel(s) of the call `back` calls ago (0 = the last one), from
     // HIP events recorded on that call's stream; -1 where the call had none
@@ -176,12 +193,17 @@ public:
 
     int frame_capacity() const { return capacity_; }
     int frame_samples() const { return (2 + cfg.header_len() + cfg.frame_length) * (cfg.fft_len + cfg.cp_len); }
+    int hdr_bits() const { return cfg.header_bits(); }   // == RxTables.hdr_bits: the row stride of d_hdr_bits
     const std::vector<std::unique_ptr<LdpcDecoder>>& decoders() const { return decoders_; }
 
 private:
     struct StreamState;
     struct Call;
+    class Worker;
     std::unique_ptr<StreamState> ss_;
+    std::unique_ptr<Worker> worker_;  // the sync stage's helper thread: started at the first call that needs it, kept
+    bool worker_failed_ = false;      // ... it could not be started: the sync stage runs on the caller's thread alone
+    int process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream);
     int stream_begin(Call& c);
     int stage_sync(Call& c);
     int stage_triggers(Call& c);

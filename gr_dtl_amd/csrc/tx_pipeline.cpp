@@ -96,6 +96,7 @@ int Transmitter::init()
     for (auto& set : cfg.pilot_symbols)
         if (set.size() != np) { set_last_error("pilot symbol sets must match the pilot carriers"); return DTL_ERR_INVALID_ARG; }
     if (!cfg.pilot_carriers.empty() && cfg.pilot_symbols.empty()) { set_last_error("pilot_symbols empty"); return DTL_ERR_INVALID_ARG; }
+    { int rc = cfg.check_header_plan(); if (rc != DTL_OK) return rc; }   // the allocator would start the payload inside the header symbols
     capacity_ = 0;
     for (int i = 0; i < cfg.frame_length; i++) capacity_ += int(cfg.occupied_carriers[i % cfg.occupied_carriers.size()].size());
     codes_.clear();
@@ -307,6 +308,8 @@ int Transmitter::process(const uint8_t* d_user, int64_t n_user, int cnst, int fe
 {
     if (n_user < 0 || (!d_user && n_user > 0) || gap < 0) { set_last_error("tx: bad input"); return DTL_ERR_INVALID_ARG; }
     if (n_user > int64_t(0xFFFFFFF0u)) { set_last_error("tx: at most 2^32 user bytes per call"); return DTL_ERR_INVALID_ARG; }
+    DeviceScope dev;
+    DTL_TRY(dev.enter(cfg.device));
     if (!uploaded_) DTL_TRY(upload_tables());
     DTL_TRY(plan(n_user, cnst, fec, first_frame_no, first_tb_no));
     const int n_frames = int(frames.size());

@@ -74,7 +74,7 @@ public:
     DevBuf d_iq, d_syms, d_hdr_bits;
     int frame_capacity() const { return capacity_; }
     int frame_samples() const { return (2 + cfg.header_len() + cfg.frame_length) * (cfg.fft_len + cfg.cp_len); }
-    int hdr_bits() const { return cfg.header_len() * int(cfg.occupied_carriers[0].size()); }
+    int hdr_bits() const { return cfg.header_bits(); }
 
     // framing state machine on lengths (host only): fills `frames` and the internal gather tables
     int plan(int64_t n_user, int cnst, int fec, int first_frame_no, int first_tb_no);

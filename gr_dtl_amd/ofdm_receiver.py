@@ -29,7 +29,7 @@ class _Cfg(C.Structure):
                 ("alist_texts", C.POINTER(C.c_char_p)), ("alist_lens", C.POINTER(C.c_size_t)),
                 ("n_mcs", C.c_int32), ("mcs_snr", C.c_void_p), ("mcs_cnst", C.c_void_p), ("mcs_fec", C.c_void_p),
                 ("initial_mcs", C.c_int32), ("decision_th", C.c_int32), ("hysteresis", C.c_double),
-                ("arith", C.c_int32), ("reserved0", C.c_int32)]
+                ("arith", C.c_int32), ("device", C.c_int32)]
 
 
 # enum dtl_arith (include/dtl_rx.h): the reference's operations / the production arithmetic
@@ -94,6 +94,7 @@ def make_cfg_struct(cfg):
     c.decision_th = 5                     # ofdm_receiver.py:167
     c.hysteresis = 1.0
     c.arith = ARITH[getattr(cfg, "arith", "gr_exact")]
+    c.device = int(getattr(cfg, "device", -1))   # DTL_DEVICE_CURRENT: the device torch has made current (one process per GPU)
     keep = (occ_len, occ, pil, psym, sw1, sw2, arr_texts, arr_lens, mcs_snr, mcs_cnst, mcs_fec, texts)
     return c, keep
 

@@ -3,6 +3,13 @@
  * adaptive-OFDM receive path.  Plain pointers and sizes only; every "d_" pointer is DEVICE
  * memory owned by the caller; `stream` is a hipStream_t passed as void* (NULL = default stream).
  * All functions return 0 (DTL_OK) or a negative dtl_status; dtl_last_error() gives the text.
+ * No C++ exception crosses this boundary: where the reference throws out of work() (std::invalid_argument "Missing
+ * constellation tag." lib/dtl/ofdm_adaptive_frame_equalizer_vcvc_impl.cc:148-150, std::runtime_error "rcv buffer does not
+ * have enough capacity!" lib/dtl/tb_decoder.cc:58-60, "Tags missing" lib/dtl/ofdm_adaptive_fec_decoder_impl.cc:121-126)
+ * the entry points return DTL_ERR_TAGS_MISSING / DTL_ERR_CAPACITY; every entry point's body runs inside a handler that
+ * turns std::bad_alloc / std::length_error into DTL_ERR_CAPACITY, std::system_error (a helper thread that cannot be
+ * started) into DTL_ERR_HIP and anything else into DTL_ERR_INTERNAL; a failed call leaves the handle usable (a receiver's
+ * stream state is reset, as after final = 1).
  * There is no CPU fallback: without a HIP device every compute entry point fails with
  * DTL_ERR_NO_DEVICE / DTL_ERR_HIP.
  *
@@ -26,7 +33,8 @@ enum dtl_status {
     DTL_ERR_TAGS_MISSING = -4,
     DTL_ERR_CAPACITY = -5,
     DTL_ERR_NO_DEVICE = -6,
-    DTL_ERR_UNSUPPORTED = -7
+    DTL_ERR_UNSUPPORTED = -7,
+    DTL_ERR_INTERNAL = -8      /* an unexpected C++ exception was stopped at the boundary (text: dtl_last_error) */
 };
 
 /* gr::dtl::constellation_type_t, include/gnuradio/dtl/ofdm_adaptive_utils.h:22-28 */
@@ -134,8 +142,12 @@ typedef struct dtl_rx_cfg {
     int32_t decision_th;             /* 5 (ofdm_receiver.py:167) */
     double hysteresis;               /* 1 */
     int32_t arith;                   /* enum dtl_arith: decoder + 16-QAM demapper arithmetic (0 = the reference's) */
-    int32_t reserved0;
+    int32_t device;                  /* HIP device the handle lives on: its tables, buffers and every kernel launch.  Each entry
+                                      * point makes it current for the duration of the call (and restores the caller's device);
+                                      * the caller's device pointers and stream must belong to it.  DTL_DEVICE_CURRENT: whatever
+                                      * device is current in the calling thread (one process per GPU with the device set once) */
 } dtl_rx_cfg;
+#define DTL_DEVICE_CURRENT (-1)
 
 /* header fields = the "header_data" dict of packet_headerparser_b; snr/noise/feedback = what
  * ofdm_adaptive_frame_equalizer_vcvc publishes per frame (tags, feedback_port, monitor) */

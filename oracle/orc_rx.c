@@ -39,7 +39,13 @@ int orc_rx_stream(const orc_cfg* cfg, const orc_ldpc* code, const orc_feedback* 
     const int N = cfg->fft_len, cp = cfg->cp_len, P = N + cp;
     const int h = cfg->header_len, L = cfg->frame_length, hdr_syms = 2 + h;
     const int cap = orc_frame_capacity(cfg);
+    /* the formatter is built from occupied_carriers[0] alone, once per header symbol (python/dtl/ofdm_receiver.py:129-130);
+     * the serializer delivers the header symbols' own sets (symbol i: set i mod n_sets): where the two differ the
+     * reference's parser and demux fall out of step -- such a plan is refused (the product refuses it at create) */
     const int hdr_bits_len = h * cfg->occ_len[0];
+    int hdr_carriers = 0;
+    for (int i = 0; i < h; i++) hdr_carriers += cfg->occ_len[i % cfg->n_occ_sets];
+    if (hdr_carriers != hdr_bits_len) return -3;
     if (hdr_bits_len < (cfg->has_fec ? 96 : 48)) return -3; /* the header fields do not fit: nothing would decode */
 
     uint8_t* trig_raw = (uint8_t*)malloc(n);

@@ -29,10 +29,12 @@ AUX = int(os.environ.get("DTL_FUZZ_AUX", "1"))     # multiplies the seed counts 
 CODES = ("n_0300_k_0152_gap_03.alist", "n_0100_k_0023_gap_10.alist", "n_0100_k_0027_gap_04.alist")
 
 
-def _scenario(oracle, dtl, rng, plans=False):
+def _scenario(oracle, dtl, rng, plans=False, rotating_sets=False):
     fft_len = int(rng.choice([64, 64, 64, 128, 128, 256, 256, 512, 1024] if plans else [64, 64, 128, 256]))
     frame_length = int(rng.integers(1, 21)) if fft_len == 64 else int(rng.integers(2, 13)) if fft_len <= 256 else int(rng.integers(2, 6))
     fec = rng.choice([None, *CODES]) if fft_len == 64 else rng.choice(CODES)
+    if rotating_sets:
+        fft_len = 64
     thr = float(rng.choice([0.95, 0.95, 0.9, 0.97]))
     knobs = {}
     if plans:   # the decoder's iteration limit and its channel sigma (never set by the reference's flowgraphs); not header
@@ -51,6 +53,26 @@ def _scenario(oracle, dtl, rng, plans=False):
         rows = tuple(tuple(complex(v) for v in rng.choice([-1.0, 1.0], len(sets[i % len(sets)])))
                      for i in range(len(sets) * int(rng.choice([1, 2, 3]))))     # row i belongs to pilot set i mod n_sets
         carriers = ((occ,), sets, rows)
+    if rotating_sets:
+        # Several data-carrier sets of DIFFERENT sizes, taken in turn symbol by symbol (ofdm_serializer_vcc /
+        # ofdm_carrier_allocator_cvc: symbol i -> set i mod n_sets).  The header symbols' sets must hold the formatter's
+        # header_len x len(occupied_carriers[0]) bits (see RxConfig::check_header_plan): with FEC (two header symbols) the
+        # first two sets have one size and a third differs; without FEC the second set already may.  frame_length is a
+        # multiple of the number of sets, so that the frame capacity does not depend on where the rotation starts (the
+        # reference's transmitter starts the payload at set header_len, its receiver's serializer at set 1).
+        used = [c for c in range(-26, 27) if c]
+        pil = (-21, -7, 7, 21)
+        base = [c for c in used if c not in pil]                    # 48 data carriers
+        def drop(k):
+            gone = set(int(c) for c in rng.choice(base, k, replace=False))
+            return tuple(c for c in base if c not in gone)
+        if fec is None:
+            occ = (tuple(base), drop(int(rng.integers(1, 9))))
+        else:
+            occ = (tuple(base), tuple(base[::-1]) if rng.integers(0, 2) else tuple(base), drop(int(rng.integers(1, 9))))
+        frame_length = len(occ) * int(rng.integers(1, 7))
+        cfg0 = dtl.ofdm_adaptive_rx_config()
+        carriers = (occ, cfg0.pilot_carriers, cfg0.pilot_symbols)
     pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=fft_len, frame_length=frame_length, fec=None if fec is None else str(fec),
                                  sync_threshold=thr, use_sync_correct=bool(rng.integers(0, 2)),
                                  llr_dist_mode=int(rng.integers(0, 2)), arith=str(rng.choice(["gr_exact", "gr_exact", "fast"])),
@@ -174,6 +196,31 @@ def test_random_scenario_with_carrier_plans(oracle, dtl, cuda, seed):
     import torch
     batch = dtl.ofdm_receiver(pcfg).work(torch.from_numpy(x).to(cuda), want=("llr", "soft_syms"))
     _assert_production_form_equals_general_form(batch, res, code is not None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("DTL_FUZZ_SETS_FIRST", "0")), int(os.environ.get("DTL_FUZZ_SETS_LAST", "60")))))
+def test_random_scenario_with_rotating_carrier_sets(oracle, dtl, cuda, seed):
+    """Data-carrier sets of different sizes taken in turn (two without FEC, three with): header bits (row stride =
+    dtl_rx_result.hdr_bits), serializer output, soft bits and every record against the oracle.  With FEC the reference's
+    transmitter and receiver rotate the payload's sets from different starts (allocator: header_len, serializer: 1,
+    python/dtl/ofdm_receiver.py:175-180), so the payload decodes to nothing -- on both sides, identically."""
+    rng = np.random.default_rng(456000 + seed)
+    pcfg, ocfg, code, x, info = _scenario(oracle, dtl, rng, rotating_sets=True)
+    assert len(pcfg.occupied_carriers) >= 2 and len({len(s) for s in pcfg.occupied_carriers}) >= 2
+    rx, res, ref = _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, max_frames=x.size // 64 + 16)
+    assert res.hdr_bits is None or res.hdr_bits.shape[1] == rx.header_len * len(pcfg.occupied_carriers[0])
+    _compare(rx, res, ref, ocfg, code is not None)
+    import torch
+    xt = torch.from_numpy(x).to(cuda)
+    batch = dtl.ofdm_receiver(pcfg).work(xt, want=("llr", "soft_syms"))
+    _assert_production_form_equals_general_form(batch, res, code is not None)
+    cuts = sorted(set(int(c) for c in rng.integers(1, max(x.size, 2), 5))) if x.size > 1 else []
+    streamed = _feed_all(dtl.ofdm_receiver(pcfg), xt, cuts)
+    if pcfg.use_sync_correct and not np.array_equal(streamed[4], batch.fixed_triggers):
+        np.testing.assert_array_equal(streamed[3], batch.raw_triggers)
+        return
+    _assert_same(batch, streamed)
 
 
 @pytest.mark.gpu
