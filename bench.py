@@ -10,11 +10,13 @@ Workload (config.workload): BASELINE.json configs[2] -- 256-subcarrier OFDM, 16-
 `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run on 127.0.0.1); under a launcher it reads
 RANK / LOCAL_RANK / WORLD_SIZE from the environment and --gpus must equal WORLD_SIZE.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (LDPC BP) with SURVEY 8(d)'s
-algorithmic bytes per sample (and carries `saturated`: the same kernel at ~9 iterations per codeword);
-`cpu_baseline` times the CPU oracle (a port of the reference chain, see oracle/) on a bounded sample of the same
-stream; `extra` holds the same step in the production arithmetic, further operating points and, for N > 1, the
-root-fed scatter / decode / gather times.
+Prints ONE JSON line on rank 0.  `roofline` prices the kernel with the largest measured device time per step (HIP events
+around every launch of one extra call: dtl_rx_kernel_split) with SURVEY 8(d)'s algorithmic bytes per sample (and carries
+`saturated`: the decoder kernel at ~9 iterations per codeword); `cpu_baseline` times the CPU oracle (a port of the reference
+chain, see oracle/) on a bounded sample of the same stream; `comparable_18dB` is the same batch at round 2's operating
+point (always measured: the round-over-round figure); `extra` holds the other BASELINE configs that fit one GPU
+(`workloads`: c2, c5), the step in the production arithmetic, further operating points, host-fed operation and, for
+N > 1, the root-fed scatter / decode / gather times with and without overlap.
 """
 import argparse
 import json
@@ -36,11 +38,20 @@ WORKLOADS = {
                min_crc_ok_frac=0.85, desc="64-subcarrier OFDM, QPSK, LDPC n=300 k=152, 4k-frame batch"),
     "c3": dict(fft_len=256, frame_length=20, cnst=4, esn0_db=23.0, sync_threshold=0.95, frames=65536, bytes_per_sample=8.13,
                min_crc_ok_frac=0.85, desc="256-subcarrier OFDM, 16-QAM, LDPC(300,152), 64k-frame batch"),
+    # BASELINE configs[4]: adaptive mixed-MCS stream, 1024-point FFT (768 data + 64 pilot carriers), frame_length 10 (the
+    # header's 12-bit length field: SURVEY 5), the reference's four constellations in turn -- the MCS changes every
+    # `seg_frames` frames (a transport block is sized to a frame at its MCS and never spans an MCS change: one PDU per
+    # segment).  Es/N0 of a unit-energy carrier symbol (QPSK carriers sit 6 dB lower, lib/dtl/constellation.cc:19-23).
+    # bytes_per_sample: measured per run (8 + user bytes out / samples: 8.03 .. 8.11 over the mix).
+    "c5": dict(fft_len=1024, frame_length=10, cnst=(1, 2, 3, 4), seg_frames=8, esn0_db=22.0, sync_threshold=0.95, frames=28672,
+               bytes_per_sample=None, min_crc_ok_frac=0.85,
+               desc="adaptive mixed-MCS stream (BPSK, QPSK, 8PSK, 16-QAM in turn, 8 frames each), 1024-pt FFT, LDPC(300,152), 28k-frame batch"),
 }
 # further Es/N0 points of a workload reported in `extra` (single-GPU runs).  C3 at 18 dB is the decoder's worst case
 # (every frame found, no block decodable: 8.5 iterations per codeword, 41 % of the codewords at the limit -- round 2's
 # headline point), 20 dB the middle of the blocks' waterfall.
 OTHER_POINTS = {"c3": (18.0, 20.0), "c2": (14.0,)}
+COMPARABLE_POINT = {"c3": 18.0}      # measured in EVERY run (also with --no-extras): round 2's headline point
 ES = {1: 1.0, 2: 0.25, 3: 1.0, 4: 1.0}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ROOT_FED_TIMEOUT_S = float(os.environ.get("DTL_BENCH_ROOT_FED_TIMEOUT", "240"))  # watchdog of the N > 1 exchange
@@ -59,41 +70,66 @@ def build_config(dtl, w):
     return cfg
 
 
+def tb_user_bytes(frame_capacity, bps, n_code=300, k_code=152):
+    """user bytes of one transport block of the LDPC(300,152) code sized to a frame (tb_encoder split) and its bytes on air"""
+    frame_bytes = frame_capacity * bps // 8
+    ncws = 1 + frame_bytes * 8 // n_code if frame_bytes * 8 > n_code else 1
+    tb_payload = ncws * k_code // 8 - 4
+    return tb_payload, (ncws * (n_code - k_code) + (tb_payload + 4) * 8) / 8.0, frame_bytes
+
+
 def synth_stream(dtl, cfg, w, n_frames, device, seed, lead=True, tail=True):
     """Synthetic AWGN IQ frames of the named FFT/codeword sizes: independent random payload for every frame,
     framed / LDPC-encoded / OFDM-modulated on the GPU by the product's own transmitter
     (gr_dtl_amd.ofdm_transmitter.work_device), 100 leading zeros, one frame of trailing zeros, plus
-    independent complex AWGN.  -> (iq, frames, user bytes sent, user tensor)"""
+    independent complex AWGN.  A workload whose `cnst` is a tuple is a mixed-MCS stream: segments of `seg_frames`
+    frames, the constellations in turn, frame / block numbers running on.  -> (iq, frames, user bytes sent, user tensor)"""
     import torch
     from gr_dtl_amd.ofdm_transmitter import ofdm_transmitter
     tx = ofdm_transmitter(cfg)
-    bps = int(w["cnst"])
-    frame_bytes = tx.frame_capacity * bps // 8
     g = torch.Generator(device=device)
     g.manual_seed(0xD71 + seed)
-    # user bytes that fill n_frames frames: whole transport blocks of the LDPC(300,152) code (tb_encoder split)
-    n_code, k_code = 300, 152
-    ncws = 1 + frame_bytes * 8 // n_code if frame_bytes * 8 > n_code else 1
-    tb_payload = ncws * k_code // 8 - 4
-    tb_coded_bytes = (ncws * (n_code - k_code) + (tb_payload + 4) * 8) / 8.0
-    n_user = int(n_frames * frame_bytes / tb_coded_bytes) * tb_payload
-    user = torch.randint(0, 256, (n_user,), dtype=torch.uint8, device=device, generator=g)
-    iq, hdrs, _ = tx.work_device(user, w["cnst"], "fec_1")
+    mixed = not isinstance(w["cnst"], int)
+    parts, n_sent, n_user_total, user = [], 0, 0, None
+    if not mixed:
+        # user bytes that fill n_frames frames: whole transport blocks of the LDPC(300,152) code (tb_encoder split)
+        tb_payload, tb_coded_bytes, frame_bytes = tb_user_bytes(tx.frame_capacity, int(w["cnst"]))
+        n_user_total = int(n_frames * frame_bytes / tb_coded_bytes) * tb_payload
+        user = torch.randint(0, 256, (n_user_total,), dtype=torch.uint8, device=device, generator=g)
+        iq, hdrs, _ = tx.work_device(user, w["cnst"], "fec_1")
+        parts.append(iq.reshape(-1))
+        n_sent = len(hdrs)
+        del iq
+    else:
+        frame_no = tb_no = 0
+        seg = int(w["seg_frames"])
+        k = 0
+        while n_sent < n_frames:
+            cnst = int(w["cnst"][k % len(w["cnst"])])
+            k += 1
+            tb_payload, tb_coded_bytes, frame_bytes = tb_user_bytes(tx.frame_capacity, cnst)
+            n_blocks = max(1, int(seg * frame_bytes / tb_coded_bytes))
+            u = torch.randint(0, 256, (n_blocks * tb_payload,), dtype=torch.uint8, device=device, generator=g)
+            iq, hdrs, _ = tx.work_device(u, cnst, "fec_1", first_frame_no=frame_no, first_tb_no=tb_no)
+            parts.append(iq.reshape(-1))
+            frame_no = (frame_no + len(hdrs)) & 0xFFF
+            tb_no += n_blocks
+            n_sent += len(hdrs)
+            n_user_total += int(u.numel())
     # 100 zeros in front (qa_ofdm_adaptive_txrx.py:82-83), one frame of zeros behind; a stream assembled from several
     # calls (the transmitter's 32-bit offsets end at ~4 G coded bits: 256 k frames of C3) takes them once
-    parts = [iq.reshape(-1)]
     if lead:
         parts.insert(0, torch.zeros(100, dtype=torch.complex64, device=device))
     if tail:
         parts.append(torch.zeros(tx.frame_samples, dtype=torch.complex64, device=device))
     x = torch.cat(parts) if len(parts) > 1 else parts[0].clone()
-    del iq
-    nv = w["fft_len"] * ES[w["cnst"]] / 10 ** (w["esn0_db"] / 10)
+    del parts
+    nv = w["fft_len"] * (1.0 if mixed else ES[w["cnst"]]) / 10 ** (w["esn0_db"] / 10)
     g.manual_seed(1234 + seed)
     noise = torch.randn((x.numel(), 2), generator=g, device=device, dtype=torch.float32) * float(np.sqrt(nv / 2))
     x += torch.view_as_complex(noise)
     del noise
-    return x, len(hdrs), n_user, user
+    return x, n_sent, n_user_total, user
 
 
 def cpu_baseline(cfg, w, x_host, n_frames_sample, frame_samples, cores, single_frames=1024):
@@ -244,7 +280,122 @@ def decode_stats(rx, x, res, n_user):
             "codewords": int(res.n_codewords), "payload_bytes": int(res.n_payload_bytes), "user_bytes_sent": int(n_user)}
 
 
-def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2, gloo=False):
+KERNEL_LIMITER = {"sync_edges_kernel": "f64_valu (exact per-output window test)", "header_kernel": "latency / LDS",
+                  "frame_eq_kernel": "f32_valu", "demap_kernel": "f32_valu (exp / log of the exact-MAP demapper)",
+                  "ldpc_bp_np_kernel": "fp64_valu", "tb_check_kernel + compaction": "latency"}
+
+
+def kernel_split(rx, x):
+    """One extra, untimed call with HIP events around every kernel launch (dtl_rx_kernel_split) ->
+    {kernel: {ms: summed over its launches, launches, longest_launch_ms}}, the kernel with the largest sum first."""
+    rx.work(x, want=("kernel_split",), copy_outputs=False)
+    ks = rx.kernel_split()
+    rows = {k: {"ms": round(v[0], 4), "launches": v[1], "longest_launch_ms": round(v[2], 4)} for k, v in ks.items() if v[1]}
+    return dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms"]))
+
+
+def roofline_of(split, alg_bytes, traffic=None):
+    """achieved = whole-chain algorithmic bytes of the samples a kernel serves per launch / its launch
+    duration; for a kernel launched several times per step bytes and time are summed over the step's launches.  The
+    line's kernel is the one with the largest MEASURED device time per step."""
+    name, top = next(iter(split.items()))
+    ach = alg_bytes / (top["ms"] * 1e-3) / 1e9 if top["ms"] > 0 else 0.0
+    return {"bound": "hbm", "limiter": KERNEL_LIMITER.get(name, "?"), "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic, "kernel_ms": top["ms"],
+            "launches_per_step": top["launches"], "algorithmic_bytes_per_launch": int(alg_bytes / max(top["launches"], 1)),
+            "kernel_ms_per_step": {k: v["ms"] for k, v in split.items()}}
+
+
+def workload_record(dtl, name, device, steps, barrier, arith, seed):
+    """One of the other BASELINE configs as its own measurement: stream, W untimed + K timed steps, decode statistics,
+    measured kernel split, roofline fraction of its longest kernel."""
+    import torch
+    w = dict(WORKLOADS[name])
+    cfg = build_config(dtl, w)
+    cfg.arith = arith
+    rx = dtl.ofdm_receiver(cfg)
+    x, n_frames, n_user, _ = synth_stream(dtl, cfg, w, w["frames"], device, seed=seed)
+    torch.cuda.synchronize()
+    elapsed, res, t_ldpc, t_payload, stage = timed_steps(rx, x, steps, 2, barrier)
+    st = decode_stats(rx, x, res, n_user)
+    st["crc_ok_frac"] = round(st["tbs_crc_ok"] / max(1, st["tbs"]), 4)
+    bps = w["bytes_per_sample"] or (8.0 + st["payload_bytes"] / x.numel())
+    split = kernel_split(rx, x)
+    ms = elapsed / steps * 1e3
+    rec = {"workload": w["desc"], "fft_len": w["fft_len"], "frames": n_frames, "samples": int(x.numel()), "esn0_db": w["esn0_db"],
+           "arith": arith, "ms_per_step": round(ms, 3), "value": round(x.numel() * steps / elapsed / 1e6, 3), "unit": "Msamples/s",
+           "bytes_per_sample": round(bps, 3), "kernel_sum_ms": round(sum(v["ms"] for v in split.values()), 3),
+           "host_stage_ms": [round(float(v) / steps, 3) for v in stage[:6]],
+           "roofline": roofline_of(split, bps * x.numel()), "stats": st}
+    if st["crc_ok_frac"] < w["min_crc_ok_frac"]:
+        rec["error"] = "only %.1f %% of the transport blocks pass their CRC-32 at this operating point" % (100 * st["crc_ok_frac"])
+    del x, res, rx
+    return rec
+
+
+def host_fed_record(dtl, rx, x, n_slices=16):
+    """Host buffers in, host buffers out (the deployment of python/dtl/ofdm_receiver.py:59-246: the hier block's ports are
+    host ring buffers): the stream sits in page-locked HOST memory and reaches the device slice by slice, the copy of
+    slice k+1 (a second stream, a second device buffer) running under the decode of slice k (ofdm_receiver.feed); decoded
+    bytes go back to pinned host memory.  Reported next to the link's own rate for the same slices (copies alone) and
+    checked against the resident-input result byte for byte.  Never the bench's `value`."""
+    import torch
+    dev = x.device
+    n = x.numel()
+    ref = rx.work(x)
+    want = ref.payload.clone()
+    host = torch.empty(n, dtype=torch.complex64, pin_memory=True)
+    host.copy_(x)
+    cuts = [(n * k // n_slices) & ~4095 for k in range(n_slices)] + [n]
+    sl = [(cuts[k], cuts[k + 1]) for k in range(n_slices) if cuts[k + 1] > cuts[k]]
+    biggest = max(b - a for a, b in sl)
+    bufs = [torch.empty(biggest, dtype=torch.complex64, device=dev) for _ in range(2)]
+    out_host = torch.empty(max(int(want.numel()), 1), dtype=torch.uint8, pin_memory=True)
+    copy_stream = torch.cuda.Stream(device=dev)
+    ev = [torch.cuda.Event() for _ in range(2)]
+    torch.cuda.synchronize()
+    # (a) the link alone: the same slices, copies only
+    t0 = time.perf_counter()
+    with torch.cuda.stream(copy_stream):
+        for k, (a, b) in enumerate(sl):
+            bufs[k % 2][:b - a].copy_(host[a:b], non_blocking=True)
+    copy_stream.synchronize()
+    t_link = time.perf_counter() - t0
+
+    def run():
+        got, at = [], 0
+        with torch.cuda.stream(copy_stream):
+            bufs[0][:sl[0][1] - sl[0][0]].copy_(host[sl[0][0]:sl[0][1]], non_blocking=True)
+            ev[0].record(copy_stream)
+        for k, (a, b) in enumerate(sl):
+            if k + 1 < len(sl):        # slice k+1 into the other buffer: feed(k-1), its last reader, has returned
+                a2, b2 = sl[k + 1]
+                with torch.cuda.stream(copy_stream):
+                    bufs[(k + 1) % 2][:b2 - a2].copy_(host[a2:b2], non_blocking=True)
+                    ev[(k + 1) % 2].record(copy_stream)
+            torch.cuda.current_stream().wait_event(ev[k % 2])
+            res = rx.feed(bufs[k % 2][:b - a], final=(k + 1 == len(sl)))
+            m = int(res.payload.numel())
+            if m:
+                out_host[at:at + m].copy_(res.payload, non_blocking=True)
+                at += m
+        torch.cuda.synchronize()
+        return at
+    rx.reset()
+    run()                                                   # warm-up (buffers of the streamed path)
+    rx.reset()
+    t0 = time.perf_counter()
+    n_out = run()
+    t_fed = time.perf_counter() - t0
+    same = n_out == int(want.numel()) and bool(torch.equal(out_host[:n_out], want.cpu()))
+    link = n * 8 / t_link / 1e9
+    return {"slices": len(sl), "samples": int(n), "ms": round(t_fed * 1e3, 3), "msamples_per_s": round(n / t_fed / 1e6, 1),
+            "GBps": round(n * 8 / t_fed / 1e9, 2), "link_GBps_copies_alone": round(link, 2),
+            "fraction_of_link_rate": round((n * 8 / t_fed / 1e9) / link, 4), "bytes_identical_to_resident_input": same,
+            "payload_bytes": int(n_out)}
+
+
+def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2, gloo=False, n_pieces=8):
     """SURVEY 8(e) "report both": ONE rank holds the whole stream (world x the per-GPU batch), scatter over xGMI ->
     decode -> gather; times of the three phases, max over ranks (tools/root_fed.py is the stand-alone form)."""
     import torch
@@ -267,6 +418,7 @@ def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2, gloo
             x = x.cpu()
     dist.broadcast(meta, 0)
     n_frames, total = int(meta[0]), int(meta[1])
+    from gr_dtl_amd.sharding import decode_pieces, scatter_pieces
     best = None
     for _ in range(1 + steps):                                # first pass = warm-up (RCCL channel set-up)
         torch.cuda.synchronize(); dist.barrier()
@@ -287,11 +439,36 @@ def root_fed_record(dtl, cfg, w, rx, frames_per_gpu, dist, device, steps=2, gloo
         if best is None or sum(cur) < sum(best[:3]):
             n_got = 0 if got is None else int(got.numel() if hasattr(got, "numel") else got.size)
             best = cur + (n_got, int(len(recs)) if recs is not None else 0)
+    # the same with the hand-over overlapped: every rank's block in `n_pieces` pieces, piece k decoded (feed) while the
+    # pieces behind it are in flight (sharding.scatter_pieces / decode_pieces)
+    best2 = None
+    for _ in range(1 + steps):
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        feed = scatter_pieces(x, n_frames, rx.frame_samples, 100, total, dist, device=exch, n_pieces=n_pieces)
+        res = decode_pieces(rx, feed, device=device)
+        feed.finish()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        data, tbs = owned_payload(res, feed.plan, on_device=not gloo)
+        got, recs = gather_results(data, tbs, dist, device=exch)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        cur = (t1 - t0, t2 - t1)
+        if best2 is None or sum(cur) < sum(best2[:2]):
+            n_got = 0 if got is None else int(got.numel() if hasattr(got, "numel") else got.size)
+            best2 = cur + (n_got, int(len(recs)) if recs is not None else 0)
     (ts, _), (td, _), (tg, _) = (combine(v, [0], dist, exch) for v in best[:3])
-    return {"frames": n_frames, "samples": total, "scatter_ms": round(ts * 1e3, 3), "decode_ms": round(td * 1e3, 3),
-            "gather_ms": round(tg * 1e3, 3), "msamples_per_s_decode_only": round(total / td / 1e6, 1),
-            "msamples_per_s_with_exchange": round(total / (ts + td + tg) / 1e6, 1),
-            "payload_bytes": best[3], "blocks": best[4],
+    (tsd, _), (tg2, _) = (combine(v, [0], dist, exch) for v in best2[:2])
+    return {"frames": n_frames, "samples": total, "world_size": world,
+            "one_shot": {"scatter_ms": round(ts * 1e3, 3), "decode_ms": round(td * 1e3, 3), "gather_ms": round(tg * 1e3, 3),
+                         "msamples_per_s_decode_only": round(total / td / 1e6, 1),
+                         "msamples_per_s_with_exchange": round(total / (ts + td + tg) / 1e6, 1),
+                         "payload_bytes": best[3], "blocks": best[4]},
+            "overlapped": {"pieces": n_pieces, "scatter_and_decode_ms": round(tsd * 1e3, 3), "gather_ms": round(tg2 * 1e3, 3),
+                           "msamples_per_s_with_exchange": round(total / (tsd + tg2) / 1e6, 1),
+                           "payload_bytes": best2[2], "blocks": best2[3],
+                           "same_payload_as_one_shot": best2[2] == best[3] and best2[3] == best[4]},
             "backend": "gloo (host-staged rehearsal)" if gloo else "nccl (RCCL, point-to-point over xGMI)"}
 
 
@@ -356,7 +533,9 @@ def main():
                 emit(line)
             print("bench.py: rank %d: root-fed exchange timed out, exiting with status 3" % rank, file=sys.stderr, flush=True)
             os._exit(3)
-        timer = threading.Timer(ROOT_FED_TIMEOUT_S, give_up)
+        # rank 0 goes first: under torch.distributed.run the agent sends SIGTERM to every surviving rank as soon as ONE rank
+        # exits non-zero, so a peer whose timer fired a moment earlier would take rank 0 down before its line is out
+        timer = threading.Timer(ROOT_FED_TIMEOUT_S + (0.0 if rank == 0 else 5.0), give_up)
         timer.daemon = True
         timer.start()
         try:
@@ -458,63 +637,78 @@ def main():
     out = None
     if rank == 0:
         st = decode_stats(rx, x, res, n_user)
-        alg_bytes = w["bytes_per_sample"] * n_samples            # bytes/sample x samples per launch
-        traffic = traffic_b = None
+        bytes_per_sample = w["bytes_per_sample"] or (8.0 + st["payload_bytes"] / n_samples)
+        alg_bytes = bytes_per_sample * n_samples                 # bytes/sample x samples per launch
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        tdoc = {}
         if os.path.exists(tpath):
             try:
                 tdoc = json.load(open(tpath))
-                traffic = tdoc.get("ldpc_bp_kernel_hbm_bytes_per_launch")
-                traffic_b = tdoc.get("phase_b_hbm_bytes_per_step")
             except Exception:
-                traffic = traffic_b = None
+                tdoc = {}
         st["crc_ok_frac"] = round(st["tbs_crc_ok"] / max(1, st["tbs"]), 4)
         # user bytes delivered / user bytes sent: 0 means the link carries nothing at this operating point
         st["goodput_bytes_frac"] = round(st["payload_bytes"] / max(1, st["user_bytes_sent"]), 4)
         st.update({"ldpc_kernel_ms": round(t_ldpc, 3), "payload_kernels_ms": round(t_payload, 3),
                    "host_stage_ms": [round(float(v) / args.steps, 3) for v in stage[:6]],
-                   "whole_chain_hbm_GBps": round(w["bytes_per_sample"] * value / 1e3, 2),
-                   "whole_chain_hbm_frac": round(w["bytes_per_sample"] * value / 1e3 / world / HBM_PEAK_GBPS, 5)})
-        def kernel_line(name, limiter, ms, launches, hbm_traffic):
-            ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"kernel": name, "limiter": limiter, "kernel_ms": round(ms, 3), "launches_per_step": launches,
-                    "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": hbm_traffic}
-        k_ldpc = kernel_line("ldpc_bp_np_kernel", "fp64_valu", t_ldpc, 1, traffic)
-        # phase B is TWO kernels per chunk of frames (frame_eq_kernel: FFT + equaliser + SNR estimate, ~43 % of the time;
-        # demap_kernel: exact-MAP soft demapper, ~57 %): neither alone is longer than the decoder's one launch unless
-        # phase B takes more than 1.75 x the decoder's time, so the decoder stays the line's kernel below that
-        k_payload = kernel_line("phase B = frame_eq_kernel + demap_kernel (FFT + equaliser + SNR estimate; soft demapper)", "f32_valu",
-                                t_payload, "one pair per chunk of ~8192 frames", traffic_b)
-        first, second = (k_ldpc, k_payload) if 1.75 * t_ldpc >= t_payload else (k_payload, k_ldpc)
-        roof = {"bound": "hbm", "limiter": first["limiter"], "kernel": first["kernel"], "achieved": first["achieved"],
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": first["frac"], "traffic": first["traffic"],
-                "kernel_ms": first["kernel_ms"], "launches_per_step": first["launches_per_step"],
-                "algorithmic_bytes_per_launch": int(alg_bytes), "second_kernel": second,
-                "note": "the single kernel with the longest duration in the step (rocprofv3 --stats of the same command: "
-                        "profiles/r03/c3_kernel_stats.csv); achieved = SURVEY 8(d) whole-chain algorithmic bytes of the samples "
-                        "it serves per launch / its launch duration (HIP events on the launch stream inside dtl_rx_process; "
-                        "second_kernel: the two kernels of phase B, bytes and time summed over their launches of one step); "
-                        "bound = the roof the metric names "
-                        "(HBM), limiter = what actually holds the kernel (the decoder: FP64 VALU, IEEE divisions -- see "
-                        "`saturated` for its instruction-bound fraction; phase B: f32 VALU, exp / log of the exact-MAP demapper)"}
+                   "whole_chain_hbm_GBps": round(bytes_per_sample * value / 1e3, 2),
+                   "whole_chain_hbm_frac": round(bytes_per_sample * value / 1e3 / world / HBM_PEAK_GBPS, 5)})
+        # which kernel is the longest is MEASURED: one extra untimed call with HIP events around every launch
+        split = kernel_split(rx, x)
+        top = next(iter(split))
+        roof = roofline_of(split, alg_bytes)
+        if top == "ldpc_bp_np_kernel" and t_ldpc > 0:
+            # its duration inside the TIMED steps (event pair of every timed call, read behind the loop): the line's figure
+            roof["kernel_ms"] = round(t_ldpc, 3)
+            roof["achieved"] = round(alg_bytes / (t_ldpc * 1e-3) / 1e9, 2)
+            roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBPS, 5)
+        # HBM bytes of that kernel from the PMC counters: collected on the builder's box with rocprofv3 --pmc in separate
+        # passes (profiles/README.md), NOT in this run
+        key = {"ldpc_bp_np_kernel": "ldpc_bp_kernel_hbm_bytes_per_launch", "demap_kernel": "demap_kernel_hbm_bytes_per_step",
+               "frame_eq_kernel": "frame_eq_kernel_hbm_bytes_per_step"}.get(top)
+        if key and tdoc.get(key) is not None:
+            traffic, traffic_src = tdoc.get(key), "profiles/traffic_%s.json (builder box, static: rocprofv3 --pmc passes, not measured in this run)" % args.workload
+        roof["traffic"], roof["traffic_source"] = traffic, traffic_src
+        roof["phase_b"] = {"kernels": "frame_eq_kernel + demap_kernel", "ms_in_timed_steps": round(t_payload, 3),
+                           "frac": round(alg_bytes / (t_payload * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if t_payload > 0 else None,
+                           "traffic": tdoc.get("phase_b_hbm_bytes_per_step")}
+        roof["note"] = ("kernel = the one with the largest measured device time per step (dtl_rx_kernel_split: HIP events on the "
+                        "launch stream around every launch of one untimed call; rocprofv3 --stats of the same command: profiles/r04/"
+                        "c3_kernel_stats.csv); achieved = SURVEY 8(d) whole-chain algorithmic bytes of the samples it serves per "
+                        "launch / its launch duration; bound = the roof the metric names (HBM), limiter = what actually holds the "
+                        "kernel (`saturated`: the decoder's instruction-bound fraction at ~9 iterations per codeword)")
         out = {
             "metric": "Msamples/s thru OFDM RX (sync>FFT>eq>demap>LDPC)", "value": round(value, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (sync/FFT/eq/demap) + f64 (LDPC BP)", "data": "synthetic (unique random payload per frame, product GPU TX + AWGN)",
             "config": {"workload": w["desc"], "fft_len": w["fft_len"], "frames_per_gpu": n_frames,
-                       "samples_per_gpu": n_samples, "constellation": int(w["cnst"]), "esn0_db": w["esn0_db"],
+                       "samples_per_gpu": n_samples, "constellation": w["cnst"] if isinstance(w["cnst"], int) else list(w["cnst"]),
+                       "esn0_db": w["esn0_db"],
                        "sync_threshold": w["sync_threshold"], "ldpc": "n=300 k=152, <=15 it, f64 LR-domain SPA",
                        "arith": args.arith,
                        "operating_point": "lowest Es/N0 on a 1 dB grid at which the link works with the reference's default "
                                           "sync_threshold 0.95: >= 99 % of the frames decoded AND >= 90 % of the transport "
-                                          "blocks CRC-ok (DESIGN.md 6).  Round 2's line ran the same batch at 18 dB (all frames "
-                                          "found, no block decodable: the decoder's worst case) -- that point and 20 dB are in "
-                                          "extra.other_operating_points",
+                                          "blocks CRC-ok (DESIGN.md 6).  NOT comparable with round 2's line, which ran the same "
+                                          "batch at 18 dB (all frames found, no block decodable: the decoder's worst case): "
+                                          "that point is measured in every run -> `comparable_18dB`",
                        "parallelism": "frame-batch shard per GPU (dp%d), no data-path collective" % world},
             "roofline": roof,
             "stats": st,
         }
+    # the round-over-round figure: the same batch at round 2's operating point, in EVERY run (one rank's own shard)
+    if args.workload in COMPARABLE_POINT and args.esn0 is None and world == 1:
+        wc = dict(w, esn0_db=COMPARABLE_POINT[args.workload])
+        xc, nfc, nuc, _ = synth_stream(dtl, cfg, wc, n_frames_req, device, seed=rank)
+        ec, resc, lc, pc, _ = timed_steps(rx, xc, 3, 1, barrier)
+        if rank == 0:
+            out["comparable_18dB"] = {"esn0_db": wc["esn0_db"], "arith": args.arith, "ms_per_step": round(ec / 3 * 1e3, 3),
+                                      "value": round(xc.numel() * 3 / ec / 1e6, 3), "unit": "Msamples/s",
+                                      "ldpc_kernel_ms": round(lc, 3), "payload_kernels_ms": round(pc, 3),
+                                      "bp_iterations_per_tb": round(float(resc.tbs["avg_it"].mean()) if len(resc.tbs) else 0.0, 3),
+                                      "note": "round 2's headline operating point (8.5 BP iterations per codeword): compare THIS across rounds"}
+        del xc, resc
     if not args.no_extras:
         if rank == 0 and world == 1:
             # (2) the decoder kernel under load (~9 iterations per codeword), both arithmetics
@@ -527,6 +721,8 @@ def main():
             # (3) the same workload at other operating points (decoder load falls with Es/N0)
             pts = []
             for esn0 in OTHER_POINTS.get(args.workload, ()):
+                if esn0 == COMPARABLE_POINT.get(args.workload):
+                    continue                                   # measured above in every run (comparable_18dB)
                 w3 = dict(w, esn0_db=esn0)
                 x3, nf3, nu3, _ = synth_stream(dtl, cfg, w3, n_frames_req, device, seed=rank)
                 e3, res3, l3, p3, _ = timed_steps(rx, x3, 3, 1, barrier)
@@ -536,6 +732,19 @@ def main():
                 pts.append(rec)
                 del x3, res3
             extras["other_operating_points"] = pts
+            # (4) the other BASELINE configs that fit one GPU, each as its own measurement (configs[1], configs[4])
+            extras["workloads"] = {}
+            for name in ("c2", "c5"):
+                if name != args.workload:
+                    try:
+                        extras["workloads"][name] = workload_record(dtl, name, device, args.steps, barrier, args.arith, seed=rank)
+                    except Exception as e:   # the headline must survive a failure of a secondary record
+                        extras["workloads"][name] = {"error": repr(e)[:300]}
+            # (5) host buffers in, host buffers out: pinned host stream, copy of slice k+1 under the decode of slice k
+            try:
+                extras["host_fed"] = host_fed_record(dtl, rx, x)
+            except Exception as e:
+                extras["host_fed"] = {"error": repr(e)[:300]}
         if world > 1:
             # (4) root-fed operation (scatter / decode / gather) behind a watchdog: it is the one part of this file no
             # 1-GPU box can rehearse over RCCL

@@ -2,6 +2,7 @@
 #include "../../include/dtl_rx.h"
 
 #include "dtl_common.h"
+#include "dtl_guard.h"
 #include "ldpc_bp.h"
 #include "rx_kernels.h"
 #include "rx_pipeline.h"
@@ -28,45 +29,7 @@ void set_last_error(const char* msg) noexcept
 void set_last_error(const std::string& msg) noexcept { set_last_error(msg.c_str()); }
 const char* last_error() noexcept { return g_last_error; }
 
-namespace {
-// Every extern "C" entry point runs its body through this: no C++ exception leaves the library (the caller may be C, a
-// ctypes binding or a GNU Radio scheduler thread -- an exception there is std::terminate in the caller's process).
-// The reference throws out of work() instead (lib/dtl/ofdm_adaptive_frame_equalizer_vcvc_impl.cc:148-150,
-// lib/dtl/tb_decoder.cc:58-60); here those conditions are status codes, and what is caught below is the C++ runtime's own
-// failures: host memory (std::vector / std::string growth), a thread that cannot be started.
-template <typename F>
-int guarded(const char* who, F&& body) noexcept
-{
-    char text[960];
-    try {
-        return body();
-    } catch (const std::bad_alloc&) {
-        std::snprintf(text, sizeof(text), "%s: out of host memory (std::bad_alloc)", who);
-        set_last_error(text);
-        return DTL_ERR_CAPACITY;
-    } catch (const std::length_error& e) {
-        std::snprintf(text, sizeof(text), "%s: size beyond what a host container can hold (%s)", who, e.what());
-        set_last_error(text);
-        return DTL_ERR_CAPACITY;
-    } catch (const std::system_error& e) {
-        std::snprintf(text, sizeof(text), "%s: system error (%s)", who, e.what());
-        set_last_error(text);
-        return DTL_ERR_HIP;
-    } catch (const std::exception& e) {
-        std::snprintf(text, sizeof(text), "%s: unexpected exception (%s)", who, e.what());
-        set_last_error(text);
-        return DTL_ERR_INTERNAL;
-    } catch (...) {
-        std::snprintf(text, sizeof(text), "%s: unexpected exception", who);
-        set_last_error(text);
-        return DTL_ERR_INTERNAL;
-    }
-}
-} // namespace
 } // namespace dtl
-
-#define DTL_API_BEGIN(who) return ::dtl::guarded(who, [&]() -> int {
-#define DTL_API_END });
 
 struct dtl_ldpc {
     dtl::LdpcDecoder dec;
@@ -401,6 +364,18 @@ int dtl_rx_kernel_ms(dtl_rx* h, int32_t back, double* ldpc_ms, double* payload_m
     DTL_API_BEGIN("dtl_rx_kernel_ms")
     if (!h) { dtl::set_last_error("rx_kernel_ms: null handle"); return DTL_ERR_INVALID_ARG; }
     return h->rx.kernel_times(back, ldpc_ms, payload_ms);
+    DTL_API_END
+}
+
+int dtl_rx_kernel_split(dtl_rx* h, dtl_rx_kernel_times* out)
+{
+    DTL_API_BEGIN("dtl_rx_kernel_split")
+    if (!h || !out) { dtl::set_last_error("rx_kernel_split: null argument"); return DTL_ERR_INVALID_ARG; }
+    const dtl::KernelClock& kc = h->rx.kernel_clock();
+    if (!kc.valid) { dtl::set_last_error("rx_kernel_split: the last call was not made with DTL_RX_WANT_KERNEL_SPLIT"); return DTL_ERR_INVALID_ARG; }
+    static_assert(int(dtl::KernelClock::N_KINDS) == int(DTL_K_COUNT), "kernel ids of the C ABI");
+    for (int k = 0; k < DTL_K_COUNT; k++) { out->ms[k] = kc.ms[k]; out->launches[k] = kc.launches[k]; out->longest_launch_ms[k] = kc.longest[k]; }
+    return DTL_OK;
     DTL_API_END
 }
 

@@ -26,7 +26,8 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
 int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc* frames, int n_frames,
                    const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
                    float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
-                   uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st, const FrameDesc* frames_host = nullptr);
+                   uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st, const FrameDesc* frames_host = nullptr,
+                   hipEvent_t between = nullptr /* recorded between the frame equaliser and the kernel behind it */);
 // phase B as one kernel (soft demapper in the frame equaliser's epilogue: no soft_syms hand-over buffer needed)?
 bool payload_is_fused(const RxTables& t, bool eq_rows);
 int launch_tb_check(const TbGather* tbs, int n_tbs, const uint8_t* bits, const int32_t* nit, uint8_t* staging,

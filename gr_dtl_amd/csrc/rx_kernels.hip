@@ -1992,7 +1992,7 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
                    const CfoSegment* segs, int n_segs, const cf32* taps, FrameStat* stats,
                    float* llr, cf32* eq_hard, cf32* eq_soft, cf32* soft_syms, bool soft_syms_wanted,
                    uint8_t* nofec_bytes, int32_t* nofec_info, int nofec_stride, hipStream_t st,
-                   const FrameDesc* frames_host)
+                   const FrameDesc* frames_host, hipEvent_t between)
 {
     if (n_frames <= 0) return DTL_OK;
     // frames_host: the descriptors in pinned, coherent host memory -- the frame equaliser reads them from there (32 bytes
@@ -2028,6 +2028,7 @@ int launch_payload(const RxTables& t, const cf32* iq, int64_t n, const FrameDesc
     else
         hipLaunchKernelGGL(frame_eq_kernel<false>, dim3(n_frames), dim3(t.fft_len), lds, st, t, iq, n, src, segs, n_segs, taps,
                            stats, eq_hard, eq_soft, soft_syms, nullptr, 0, copy);
+    if (between) DTL_HIP_CHECK(hipEventRecord(between, st));
     if (t.has_fec) {
         const dim3 grid(n_frames, (t.frame_capacity + 255) / 256);
         if (mode == 1) hipLaunchKernelGGL(demap_kernel<1>, grid, dim3(256), 0, st, t, frames, stats, soft_syms, llr);

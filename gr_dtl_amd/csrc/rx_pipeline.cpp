@@ -72,6 +72,50 @@ static int device_view(const HostBuf& hb, void** out)
     return DTL_OK;
 }
 
+KernelClock::~KernelClock()
+{
+    for (auto& e : pool) if (e) (void)hipEventDestroy(e);
+}
+
+void KernelClock::begin(bool enable)
+{
+    on = enable;
+    valid = false;
+    if (!enable) return;
+    used = 0;
+    spans.clear();
+}
+
+int KernelClock::mark(hipStream_t st, size_t* idx)
+{
+    if (used == pool.size()) {
+        hipEvent_t e = nullptr;
+        DTL_HIP_CHECK(hipEventCreate(&e));
+        pool.push_back(e);
+    }
+    DTL_HIP_CHECK(hipEventRecord(pool[used], st));
+    *idx = used++;
+    return DTL_OK;
+}
+
+int KernelClock::collect()
+{
+    for (int k = 0; k < N_KINDS; k++) { ms[k] = longest[k] = 0.0; launches[k] = 0; }
+    for (const Span& sp : spans) {
+        float t = 0.0f;
+        DTL_HIP_CHECK(hipEventElapsedTime(&t, pool[sp.a], pool[sp.b]));
+        ms[sp.kind] += double(t);
+        longest[sp.kind] = std::max(longest[sp.kind], double(t));
+        launches[sp.kind]++;
+    }
+    valid = true;
+    return DTL_OK;
+}
+
+// bracket one launch with the call's kernel clock (no-ops unless the call asked for the split)
+#define KC_BEGIN(stream) size_t _kc_a = 0; if (kc_.on) DTL_TRY(kc_.mark((stream), &_kc_a))
+#define KC_END(kind, stream) do { if (kc_.on) { size_t _kc_b = 0; DTL_TRY(kc_.mark((stream), &_kc_b)); kc_.span((kind), _kc_a, _kc_b); } } while (0)
+
 int DeviceScope::enter(int device)
 {
     if (device < 0) return DTL_OK;
@@ -1062,8 +1106,10 @@ int Receiver::stage_sync(Call& c)
             size_t hoff = 0;
             for (size_t c = 0; c < rg.size(); c++) {
                 const Range& r = rg[c];
+                KC_BEGIN(st);
                 DTL_TRY(launch_sync_edges(iq, r.me, r.mb, N, cfg.sync_threshold, d_edges_.as<unsigned long long>() + r.off,
                                           d_counter_.as<unsigned int>() + c, r.max_edges, metric ? metric + (r.mb - mb0) : nullptr, st));
+                KC_END(KernelClock::SYNC, st);
                 DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<unsigned>() + c, d_counter_.as<unsigned int>() + c, 4, hipMemcpyDeviceToHost, st));
                 DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.as<unsigned long long>() + hoff, d_edges_.as<unsigned long long>() + r.off,
                                              size_t(r.guess) * 8, hipMemcpyDeviceToHost, st));
@@ -1402,9 +1448,11 @@ int Receiver::speculate_headers(Call& c, int64_t limit, bool split_last)
         const int e0 = int(int64_t(n_add) * part / n_parts), e1 = int(int64_t(n_add) * (part + 1) / n_parts);
         if (e1 <= e0) continue;
         const size_t p0 = s0 + size_t(e0);
+        KC_BEGIN(c.st);
         DTL_TRY(launch_header(tab_, c.iq, c.W, cands_dev + p0, e1 - e0, d_segs_.as<CfoSegment>(),
                               int(c.segs_uploaded), d_recs_.as<HeaderRec>() + p0, d_taps.as<cf32>() + p0 * N,
                               hb ? hb + p0 * tab_.hdr_bits : nullptr, c.st));
+        KC_END(KernelClock::HEADER, c.st);
         DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + p0, d_recs_.as<HeaderRec>() + p0, size_t(e1 - e0) * sizeof(HeaderRec),
                                      hipMemcpyDeviceToHost, c.st));
         while (hdr_ev_.size() <= c.hdr_launches.size()) {
@@ -1672,9 +1720,11 @@ int Receiver::stage_frames(Call& c)
                 const int e0 = int(int64_t(n_extra) * part / n_parts), e1 = int(int64_t(n_extra) * (part + 1) / n_parts);
                 if (e1 <= e0) continue;
                 const size_t s0 = s_base + size_t(e0);
+                KC_BEGIN(st);
                 DTL_TRY(launch_header(tab_, iq, W, cands_dev + s0, e1 - e0, d_segs_.as<CfoSegment>(), n_segs,
                                       d_recs_.as<HeaderRec>() + s0, d_taps.as<cf32>() + s0 * N,
                                       hb ? hb + s0 * tab_.hdr_bits : nullptr, st));
+                KC_END(KernelClock::HEADER, st);
                 DTL_HIP_CHECK(hipMemcpyAsync(h_recs_.as<HeaderRec>() + s0, d_recs_.as<HeaderRec>() + s0,
                                              size_t(e1 - e0) * sizeof(HeaderRec), hipMemcpyDeviceToHost, st));
                 while (hdr_ev_.size() <= c.hdr_launches.size()) {
@@ -1708,12 +1758,26 @@ int Receiver::stage_frames(Call& c)
                                          size_t(f1 - f0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
         }
         if (!payload_started && ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[0], st)); payload_started = true; }
+        size_t kc_a = 0, kc_m = 0, kc_b = 0;
+        hipEvent_t between = nullptr;
+        if (kc_.on) {
+            DTL_TRY(kc_.mark(st, &kc_a));
+            if (kc_.used == kc_.pool.size()) { hipEvent_t e = nullptr; DTL_HIP_CHECK(hipEventCreate(&e)); kc_.pool.push_back(e); }
+            kc_m = kc_.used++;                       // recorded by launch_payload between its two kernels
+            between = kc_.pool[kc_m];
+        }
         DTL_TRY(launch_payload(tab_, iq, W, d_frames_.as<FrameDesc>() + f0, f1 - f0, d_segs_.as<CfoSegment>(), n_segs,
                                d_taps.as<cf32>(), d_stats_.as<FrameStat>() + f0,
                                d_llr.as<float>(), eh ? eh + size_t(f0) * L * N : nullptr, es ? es + size_t(f0) * L * N : nullptr,
                                ss_out ? ss_out + size_t(f0) * capacity_ : nullptr, (flags & RX_WANT_SOFT_SYMS) != 0,
                                nofec_bytes ? nofec_bytes + size_t(f0) * nofec_stride : nullptr,
-                               nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st, host_descs));
+                               nofec_inf ? nofec_inf + size_t(f0) * 2 : nullptr, nofec_stride, st, host_descs, between));
+        if (kc_.on) {
+            DTL_TRY(kc_.mark(st, &kc_b));
+            const bool fused = between && payload_is_fused(tab_, eh || es);
+            if (fused) kc_.span(KernelClock::FRAME_EQ, kc_a, kc_b);          // one kernel: the event between was never recorded
+            else { kc_.span(KernelClock::FRAME_EQ, kc_a, kc_m); kc_.span(KernelClock::DEMAP, kc_m, kc_b); }
+        }
         f0 = f1;
         return DTL_OK;
     };
@@ -1899,15 +1963,20 @@ int Receiver::stage_blocks(Call& c)
             bool packed = true;
             for (auto& cr : code_ranges) packed = packed && decoders_[cr.first]->packed_output_ok();
             if (packed) DTL_HIP_CHECK(hipMemsetAsync(d_cw_bits.p, 0, (size_t(bits_total) / 8 + 64 + 7) & ~size_t(7), st));
-            for (auto& cr : code_ranges)
+            for (auto& cr : code_ranges) {
+                KC_BEGIN(st);
                 DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
                                                     d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st, packed));
+                KC_END(KernelClock::LDPC, st);
+            }
             if (ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[3], st)); ev_mask_[(n_calls_ - 1) % kEvRing] |= 2u; }
+            DTL_TRY(d_payload.ensure(max_out_bytes + 64));
+            KC_BEGIN(st);
             DTL_TRY(launch_tb_check(d_tbgather_.as<TbGather>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),
                                     d_staging_.as<uint8_t>(), stride, d_tbres_.as<TbResult>(), d_len_.as<int32_t>(), st, packed));
-            DTL_TRY(d_payload.ensure(max_out_bytes + 64));
             DTL_TRY(launch_compact(d_staging_.as<uint8_t>(), stride, d_len_.as<int32_t>(), n_tbs, d_offs_.as<uint32_t>(),
                                    d_total_.as<uint32_t>(), d_payload.as<uint8_t>(), st));
+            KC_END(KernelClock::TB_CHECK, st);
             DTL_HIP_CHECK(hipMemcpyAsync(h_tbres_.p, d_tbres_.p, size_t(n_tbs) * sizeof(TbResult), hipMemcpyDeviceToHost, st));
             DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<uint8_t>() + 96, d_total_.p, 4, hipMemcpyDeviceToHost, st));
         }
@@ -1955,6 +2024,7 @@ int Receiver::stage_blocks(Call& c)
         }
     }
     DTL_HIP_CHECK(hipStreamSynchronize(st));
+    if (kc_.on) DTL_TRY(kc_.collect());
     if (cfg.has_fec && n_tbs) std::memcpy(tb_res.data(), h_tbres_.p, size_t(n_tbs) * sizeof(TbResult));
     if (!cfg.has_fec && n_frames) std::memcpy(nofec_info.data(), h_nofec_.p, size_t(n_frames) * 8);
     total_bytes = *reinterpret_cast<uint32_t*>(h_small_.as<uint8_t>() + 96);
@@ -2103,6 +2173,7 @@ int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, b
         ev_ = ev_ring_[slot];
         ev_mask_[slot] = 0;
     }
+    kc_.begin((flags & RX_WANT_KERNEL_SPLIT) != 0);
     Call c;
     c.d_iq = d_iq; c.iq = d_iq; c.n = n; c.W = W; c.flags = flags; c.final = final; c.st = st;
     // A = absolute index of the working buffer's first sample (a multiple of the sync kernel's tile, so that

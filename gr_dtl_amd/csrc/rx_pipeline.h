@@ -120,7 +120,7 @@ struct TbInfo { // mirrors dtl_rx_tb_info
 
 enum ProcessFlags : unsigned {
     RX_WANT_EQ_HARD = 1u, RX_WANT_EQ_SOFT = 2u, RX_WANT_SOFT_SYMS = 4u, RX_WANT_HDR_BITS = 8u,
-    RX_WANT_METRIC = 16u, RX_WANT_KERNEL_MS = 32u,
+    RX_WANT_METRIC = 16u, RX_WANT_KERNEL_MS = 32u, RX_WANT_KERNEL_SPLIT = 64u,
 };
 
 struct DevBuf {
@@ -150,6 +150,25 @@ struct TbSpan {
 int tb_gather_frames(const std::vector<std::pair<int, int>>& code_nk, int capacity, int max_bps, const FrameInfo* frames,
                      int64_t n_frames, std::vector<TbGather>& gathers, std::vector<TbSpan>& spans);
 
+// Per-kernel device times of ONE call (RX_WANT_KERNEL_SPLIT): an event in front of and behind every launch, on the
+// launch stream, from a pool kept by the handle; read after the call's final synchronisation.
+struct KernelClock {
+    enum Kind { SYNC = 0, HEADER, FRAME_EQ, DEMAP, LDPC, TB_CHECK, N_KINDS };
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    struct Span { int kind; size_t a, b; };
+    std::vector<Span> spans;
+    double ms[N_KINDS] = { 0 }, longest[N_KINDS] = { 0 };
+    int launches[N_KINDS] = { 0 };
+    bool valid = false;
+    ~KernelClock();
+    void begin(bool enable);                       // start of a call
+    int mark(hipStream_t st, size_t* idx);         // record the next event of the pool
+    void span(int kind, size_t a, size_t b) { spans.push_back({ kind, a, b }); }
+    int collect();                                 // behind the call's last synchronisation
+};
+
 class Receiver {
 public:
     RxConfig cfg;
@@ -168,6 +187,7 @@ public:
     // device time of the phase-B kernels and of the LDPC kernel(s) of the call `back` calls ago (0 = the last one), from
     // HIP events recorded on that call's stream; -1 where the call had none
     int kernel_times(int back, double* ldpc_ms, double* payload_ms);
+    const KernelClock& kernel_clock() const { return kc_; }
 
     // results of the last process() call
     std::vector<FrameInfo> frames;   // every trigger the demux visited, in order
@@ -201,6 +221,7 @@ private:
     struct Call;
     class Worker;
     std::unique_ptr<StreamState> ss_;
+    KernelClock kc_;
     std::unique_ptr<Worker> worker_;  // the sync stage's helper thread: started at the first call that needs it, kept
     bool worker_failed_ = false;      // ... it could not be started: the sync stage runs on the caller's thread alone
     int process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream);

@@ -147,7 +147,12 @@ class _Result(C.Structure):
                 ("pad", C.c_int32)]
 
 
-WANT = {"eq_hard": 1, "eq_soft": 2, "soft_syms": 4, "hdr_bits": 8, "metric": 16, "kernel_ms": 32}
+WANT = {"eq_hard": 1, "eq_soft": 2, "soft_syms": 4, "hdr_bits": 8, "metric": 16, "kernel_ms": 32, "kernel_split": 64}
+KERNEL_NAMES = ("sync_edges_kernel", "header_kernel", "frame_eq_kernel", "demap_kernel", "ldpc_bp_np_kernel", "tb_check_kernel + compaction")
+
+
+class KernelTimes(C.Structure):   # dtl_rx_kernel_times
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int32 * 6), ("longest_launch_ms", C.c_double * 6)]
 _FRAME_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4", C.c_double: "<f8"}[t]) for n, t in FrameInfo._fields_], align=True)
 _TB_DTYPE = np.dtype([(n, {C.c_int64: "<i8", C.c_int32: "<i4"}[t]) for n, t in TbInfo._fields_], align=True)
 
@@ -263,6 +268,7 @@ class ofdm_receiver:
         L.dtl_rx_stream_position.argtypes = [C.c_void_p]
         L.dtl_rx_stream_position.restype = C.c_int64
         L.dtl_rx_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.dtl_rx_kernel_split.argtypes = [C.c_void_p, C.POINTER(KernelTimes)]
         L.dtl_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.dtl_chanest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dtl_header_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(HeaderFields),
@@ -401,6 +407,13 @@ class ofdm_receiver:
         a, b = C.c_double(-1.0), C.c_double(-1.0)
         _lib.check(_lib.lib().dtl_rx_kernel_ms(self._h, int(back), C.byref(a), C.byref(b)))
         return (a.value if a.value >= 0 else None, b.value if b.value >= 0 else None)
+
+    def kernel_split(self):
+        """Per-kernel device times of the last call made with want=("kernel_split",): {kernel: (ms summed over its
+        launches, launches, longest single launch ms)} from HIP events around every launch (dtl_rx_kernel_split)."""
+        kt = KernelTimes()
+        _lib.check(_lib.lib().dtl_rx_kernel_split(self._h, C.byref(kt)))
+        return {KERNEL_NAMES[k]: (float(kt.ms[k]), int(kt.launches[k]), float(kt.longest_launch_ms[k])) for k in range(6)}
 
     @property
     def stream_position(self):

@@ -10,6 +10,8 @@ samples (point-to-point sends from the root: with RCCL, one xGMI link per peer, 
 frames in front, guard frames behind); `owned_blocks` keeps, on every rank, the transport blocks that START inside its own
 frames, so that the concatenation over the ranks is what one receiver would have delivered.
 """
+import ctypes as C
+
 import numpy as np
 
 
@@ -43,8 +45,47 @@ def combine(elapsed_s, counters, dist=None, device=None):
 
 
 # ------------------------------------------------------------------------------------------ root-fed operation
+# Where to cut and which blocks a rank owns is host arithmetic of the C ABI (include/dtl_rx.h: dtl_shard_plan,
+# dtl_shard_pieces, dtl_owned_blocks, dtl_owned_payload_ranges -- a C++ host shards with the same calls); the functions
+# below are thin callers.  The exchange itself is torch.distributed point-to-point (backend nccl == RCCL over xGMI).
 
 WARMUP_FRAMES = 4  # frame_detect_bb is in sync after three consistent triggers (kSyncedTh, ..._frame_detect_bb_impl.cc:21)
+PIECE_ALIGN = 4096  # the sync kernel's tile: pieces of a shard are cut at multiples of it behind the shard's start
+
+
+class _Shard(C.Structure):   # dtl_shard
+    _fields_ = [("start", C.c_int64), ("stop", C.c_int64), ("own_lo", C.c_int64), ("own_hi", C.c_int64)]
+
+
+def _clib():
+    from . import _lib
+    L = _lib.lib()
+    if not getattr(L, "_shard_declared", False):
+        L.dtl_shard_plan.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_Shard)]
+        L.dtl_shard_pieces.argtypes = [C.POINTER(_Shard), C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_int32)]
+        L.dtl_owned_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(_Shard), C.c_void_p, C.c_int64,
+                                       C.POINTER(C.c_int64)]
+        L.dtl_owned_payload_ranges.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.POINTER(C.c_int64)]
+        L._shard_declared = True
+    return L, _lib
+
+
+def _as_records(arr, dtype):
+    """record array -> contiguous array of the C layout `dtype` (fields copied by NAME; fields the caller's array does not
+    have stay zero)"""
+    arr = np.asarray(arr)
+    if arr.dtype == dtype:
+        return np.ascontiguousarray(arr)
+    out = np.zeros(len(arr), dtype=dtype)
+    for name in (arr.dtype.names or ()):
+        if name in dtype.names:
+            out[name] = arr[name]
+    return out
+
+
+def _as_shard(plan):
+    return _Shard(int(plan["start"]), int(plan.get("stop", plan["own_hi"])), int(plan["own_lo"]), int(plan["own_hi"]))
 
 
 def shard_plan(n_frames, frame_samples, lead, total_samples, world_size, rank, guard_frames=3):
@@ -54,20 +95,32 @@ def shard_plan(n_frames, frame_samples, lead, total_samples, world_size, rank, g
     that starts in the rank's last frame must be complete.  A block slightly larger than a frame's payload touches
     three frames (tail of one, a whole one, head of the next), and frames are cut at their trigger, about a symbol
     behind the nominal frame start -- hence three frames; blocks of several frame payloads need more) and the samples it OWNS ([own_lo,
-    own_hi): a transport block belongs to the rank whose range holds the trigger of the frame it starts in)."""
-    lo, hi = shard_bounds(n_frames, world_size, rank)
-    own_lo = lead + lo * frame_samples if rank else 0
-    own_hi = lead + hi * frame_samples if rank + 1 < world_size else total_samples
-    start = max(0, own_lo - max(guard_frames, WARMUP_FRAMES) * frame_samples) if rank else 0
-    stop = min(total_samples, own_hi + guard_frames * frame_samples) if rank + 1 < world_size else total_samples
-    return dict(start=int(start), stop=int(stop), own_lo=int(own_lo), own_hi=int(own_hi))
+    own_hi): a transport block belongs to the rank whose range holds the trigger of the frame it starts in).
+    (dtl_shard_plan of the C ABI)"""
+    L, _lib = _clib()
+    out = _Shard()
+    _lib.check(L.dtl_shard_plan(int(n_frames), int(frame_samples), int(lead), int(total_samples), int(world_size), int(rank),
+                                int(guard_frames), C.byref(out)))
+    return dict(start=int(out.start), stop=int(out.stop), own_lo=int(out.own_lo), own_hi=int(out.own_hi))
+
+
+def shard_pieces(plan, n_pieces, align=PIECE_ALIGN):
+    """-> ascending absolute sample positions [start, ..., stop]: the shard cut into at most n_pieces consecutive pieces
+    (dtl_shard_pieces: cuts at multiples of `align` behind the shard's start)."""
+    L, _lib = _clib()
+    bounds = np.zeros(int(n_pieces) + 1, dtype=np.int64)
+    n = C.c_int32(0)
+    sh = _as_shard(plan)
+    _lib.check(L.dtl_shard_pieces(C.byref(sh), int(n_pieces), int(align), bounds.ctypes.data, C.byref(n)))
+    return [int(v) for v in bounds[:n.value + 1]]
 
 
 def scatter_stream(x_root, n_frames, frame_samples, lead, total_samples, dist, device=None, src=0, guard_frames=3):
     """Root holds the complex64 stream `x_root` (1-D tensor; None on the other ranks); every rank returns its block
     (shard_plan) as a complex64 tensor on `device` together with the plan.  Point-to-point: the root posts one
     isend per peer (the blocks differ in length and overlap, so this is not a plain scatter), the peers one irecv;
-    with the nccl backend these are RCCL send/recv pairs over the direct xGMI links, all in flight together."""
+    with the nccl backend these are RCCL send/recv pairs over the direct xGMI links, all in flight together.
+    One-shot form: the whole block arrives before anything is decoded (scatter_pieces overlaps the two)."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     plan = shard_plan(n_frames, frame_samples, lead, total_samples, world, rank, guard_frames)
@@ -92,6 +145,121 @@ def scatter_stream(x_root, n_frames, frame_samples, lead, total_samples, dist, d
     return torch.view_as_complex(buf), plan
 
 
+class ShardFeed:
+    """A rank's block arriving piece by piece (scatter_pieces).  Iterating yields the pieces in stream order, each as
+    soon as it has arrived -- while the caller decodes piece k (ofdm_receiver.feed), pieces k+1 .. are in flight: every
+    receive was posted up front, each into its own slice of the rank's buffer (memory is not the constraint: a C3 shard
+    is 4 GB of 288), and RCCL works through them on its own stream."""
+
+    def __init__(self, plan, bounds, buf, reqs, sends):
+        self.plan, self.bounds, self._buf, self._reqs, self._sends = plan, bounds, buf, reqs, sends
+
+    def __len__(self):
+        return len(self.bounds) - 1
+
+    def __iter__(self):
+        import torch
+        start = self.plan["start"]
+        for k in range(len(self)):
+            if self._reqs is not None:
+                for q in self._reqs[k]:
+                    q.wait()          # nccl: the current stream waits for piece k; gloo: the host does
+            a, b = self.bounds[k] - start, self.bounds[k + 1] - start
+            piece = self._buf[a:b]
+            yield torch.view_as_complex(piece) if piece.dtype == torch.float32 else piece
+
+    def finish(self):
+        """root: the sends have all been handed over (call after the own pieces are decoded)"""
+        for q in self._sends:
+            q.wait()
+        self._sends = []
+
+
+def scatter_pieces(x_root, n_frames, frame_samples, lead, total_samples, dist, device=None, src=0, guard_frames=3, n_pieces=8):
+    """The pipelined form of scatter_stream ("scatter of chunk i+1 overlapped with compute of chunk i"): every
+    rank's block is cut into the same number of pieces (shard_pieces); the root posts the sends PIECE-major -- piece 0 to
+    every peer, then piece 1, ... -- so that all peers can start decoding after 1/n_pieces of the transfer; a peer posts
+    all its receives at once.  -> ShardFeed.  Legal because the receiver's streaming call returns the same frames whatever
+    the cuts (dtl_rx_process_stream), which in turn rests on the reference's per-frame reset of the equaliser state
+    (lib/dtl/ofdm_adaptive_frame_equalizer_vcvc_impl.cc:117-118,180)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    plan = shard_plan(n_frames, frame_samples, lead, total_samples, world, rank, guard_frames)
+    bounds = shard_pieces(plan, n_pieces)
+    if world == 1:
+        return ShardFeed(plan, bounds, x_root[plan["start"]:plan["stop"]], None, [])
+    if rank == src:
+        flat = torch.view_as_real(x_root.contiguous())
+        peers = []
+        for r in range(world):
+            if r == src:
+                continue
+            p = shard_plan(n_frames, frame_samples, lead, total_samples, world, r, guard_frames)
+            peers.append((r, shard_pieces(p, n_pieces)))
+        sends = []
+        for k in range(max([len(b) - 1 for _, b in peers] + [0])):
+            ops = [dist.P2POp(dist.isend, flat[b[k]:b[k + 1]], r) for r, b in peers if k + 1 < len(b)]
+            if ops:
+                sends.extend(dist.batch_isend_irecv(ops))
+        return ShardFeed(plan, bounds, x_root[plan["start"]:plan["stop"]], None, sends)
+    buf = torch.empty((plan["stop"] - plan["start"], 2), dtype=torch.float32, device=device)
+    reqs = []
+    for k in range(len(bounds) - 1):
+        a, b = bounds[k] - plan["start"], bounds[k + 1] - plan["start"]
+        reqs.append(dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf[a:b], src)]))
+    return ShardFeed(plan, bounds, buf, reqs, [])
+
+
+class ShardResult:
+    """The records of a shard decoded piece by piece, merged into what ONE call over the shard returns: frames and block
+    records concatenated (trigger positions of feed() are absolute within the shard already; a block's output offset is
+    moved behind the bytes of the earlier calls), payload bytes concatenated."""
+
+    def __init__(self):
+        self._frames, self._tbs, self._payload = [], [], []
+        self.n_payload_bytes = 0
+        self.n_payload_frames = 0
+
+    def add(self, res):
+        tbs = res.tbs.copy()
+        tbs["out_offset"] = np.where(tbs["out_offset"] >= 0, tbs["out_offset"] + self.n_payload_bytes, -1)
+        self._frames.append(res.frames.copy())
+        self._tbs.append(tbs)
+        self._payload.append(res.payload)
+        self.n_payload_bytes += int(res.payload.numel() if hasattr(res.payload, "numel") else len(res.payload))
+        self.n_payload_frames += int(res.n_payload_frames)
+
+    @property
+    def frames(self):
+        return np.concatenate(self._frames) if self._frames else np.zeros(0)
+
+    @property
+    def tbs(self):
+        return np.concatenate(self._tbs) if self._tbs else np.zeros(0)
+
+    @property
+    def payload(self):
+        import torch
+        if self._payload and hasattr(self._payload[0], "numel"):
+            return torch.cat(self._payload) if len(self._payload) > 1 else self._payload[0]
+        return np.concatenate(self._payload) if self._payload else np.zeros(0, np.uint8)
+
+
+def decode_pieces(rx, feed, device=None):
+    """ofdm_receiver.feed() over the pieces of a ShardFeed as they arrive -> ShardResult (what rx.work(whole block)
+    returns, assembled from the streamed calls)."""
+    rx.reset()
+    acc = ShardResult()
+    n = len(feed)
+    for k, piece in enumerate(feed):
+        if device is not None and not piece.is_cuda:
+            piece = piece.to(device)                          # (gloo rehearsal: the exchange is staged through the host)
+        acc.add(rx.feed(piece, final=(k + 1 == n)))
+    if n == 0:
+        rx.reset()
+    return acc
+
+
 def _unwrap(numbers, modulus=256):
     """Block numbers as a non-decreasing sequence (the header field wraps; consecutive records are < one wrap apart)."""
     numbers = np.asarray(numbers, dtype=np.int64)
@@ -106,45 +274,46 @@ def owned_blocks(frames, tbs, plan):
     block that starts in it (`tb_no`; `tb_offset` is the tail of the previous block) and blocks complete in stream
     order, so both lists are turned into running block counts (the 8-bit number unwrapped) and matched by value.
     Starts whose block never completed simply find no record; a record without a start of its own (a block flushed
-    twice around a lost frame) goes where the record before it went."""
+    twice around a lost frame) goes where the record before it went.  (dtl_owned_blocks of the C ABI)"""
+    from .ofdm_receiver import _FRAME_DTYPE, _TB_DTYPE
     if len(tbs) == 0:
         return np.zeros(0, dtype=np.int64)
-    m = (frames["payload_index"] >= 0) & (frames["payload_len"] > 0)
-    f_no = frames["tb_no"][m].astype(np.int64)
-    f_pos = frames["trigger"][m].astype(np.int64) + plan["start"]
-    if f_no.size == 0:
-        return np.zeros(0, dtype=np.int64)
-    first = np.concatenate([[True], f_no[1:] != f_no[:-1]])          # a frame that continues a block starts none
-    s_no, s_pos = f_no[first], f_pos[first]
-    s_seq = _unwrap(s_no)
-    t_no = tbs["tb_no"].astype(np.int64)
-    t_seq = _unwrap(t_no) + (t_no[0] - s_no[0]) % 256                # the first record's block started <= 255 starts in
-    at = np.searchsorted(s_seq, t_seq)
-    hit = (at < s_seq.size) & (s_seq[np.minimum(at, s_seq.size - 1)] == t_seq)
-    pos = np.where(hit, s_pos[np.minimum(at, s_seq.size - 1)], -1)
-    # records without a start inherit the previous record's position
-    idx = np.where(hit, np.arange(len(tbs)), -1)
-    idx = np.maximum.accumulate(idx)
-    pos = np.where(idx >= 0, pos[np.maximum(idx, 0)], -1)
-    return np.nonzero((pos >= plan["own_lo"]) & (pos < plan["own_hi"]))[0].astype(np.int64)
+    L, _lib = _clib()
+    fr = _as_records(frames, _FRAME_DTYPE)
+    tb = _as_records(tbs, _TB_DTYPE)
+    idx = np.zeros(len(tb), dtype=np.int64)
+    n = C.c_int64(0)
+    sh = _as_shard(plan)
+    _lib.check(L.dtl_owned_blocks(fr.ctypes.data if len(fr) else None, len(fr), tb.ctypes.data, len(tb), C.byref(sh),
+                                  idx.ctypes.data, len(idx), C.byref(n)))
+    return idx[:n.value].copy()
 
 
 def owned_payload(result, plan, on_device=False):
     """-> (bytes, tbs records) of the CRC-ok transport blocks this rank owns, in stream order.  The bytes are a uint8
-    numpy array, or with on_device=True a slice of the result's device tensor (no copy through the host)."""
+    numpy array, or with on_device=True a slice of the result's device tensor (no copy through the host).
+    (dtl_owned_blocks + dtl_owned_payload_ranges of the C ABI)"""
+    from .ofdm_receiver import _TB_DTYPE
     tbs = result.tbs
     keep = owned_blocks(result.frames, tbs, plan)
     mine = tbs[keep]
-    ok = mine[mine["crc_ok"] == 1]
     payload = result.payload
     if not on_device:
         payload = payload.cpu().numpy() if hasattr(payload, "cpu") else np.asarray(payload)
-    if len(ok) == 0:
+    if len(keep) == 0:
         return payload[:0], mine
-    offs, lens = ok["out_offset"].astype(np.int64), ok["user_bits"].astype(np.int64) // 8
-    if np.all(offs[1:] == offs[:-1] + lens[:-1]):                      # the usual case: one contiguous run of blocks
-        return payload[int(offs[0]):int(offs[-1] + lens[-1])], mine
-    parts = [payload[int(o):int(o + n)] for o, n in zip(offs, lens)]
+    L, _lib = _clib()
+    tb = _as_records(tbs, _TB_DTYPE)
+    offs, lens = np.zeros(len(keep), np.int64), np.zeros(len(keep), np.int64)
+    n = C.c_int64(0)
+    keep64 = np.ascontiguousarray(keep, dtype=np.int64)
+    _lib.check(L.dtl_owned_payload_ranges(tb.ctypes.data, len(tb), keep64.ctypes.data, len(keep64), offs.ctypes.data,
+                                          lens.ctypes.data, len(offs), C.byref(n)))
+    if n.value == 0:
+        return payload[:0], mine
+    if n.value == 1:                                                    # the usual case: one contiguous run of blocks
+        return payload[int(offs[0]):int(offs[0] + lens[0])], mine
+    parts = [payload[int(o):int(o + m)] for o, m in zip(offs[:n.value], lens[:n.value])]
     if on_device:
         import torch
         return torch.cat(parts), mine

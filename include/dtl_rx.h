@@ -173,7 +173,9 @@ enum dtl_rx_flags {
     DTL_RX_WANT_SOFT_SYMS = 4,  /* serializer output (frame_capacity per frame)                        */
     DTL_RX_WANT_HDR_BITS = 8,
     DTL_RX_WANT_METRIC = 16,    /* Schmidl-Cox metric per sample (debug)                               */
-    DTL_RX_WANT_KERNEL_MS = 32  /* stage_ms[6], [7] (device time of the LDPC / phase-B kernels) read inside the call */
+    DTL_RX_WANT_KERNEL_MS = 32, /* stage_ms[6], [7] (device time of the LDPC / phase-B kernels) read inside the call */
+    DTL_RX_WANT_KERNEL_SPLIT = 64 /* HIP events around EVERY kernel launch of the call; read with dtl_rx_kernel_split.  A
+                                 * measurement aid: the extra events open small gaps between kernels, not for timed steps */
 };
 
 /* All pointers are owned by the handle and stay valid until the next dtl_rx_process / destroy.
@@ -232,6 +234,17 @@ int64_t dtl_rx_stream_position(const dtl_rx* h);
  * calls ago (0 = the last one; the handle keeps HIP events of its last 32 calls, recorded on each call's stream);
  * -1 where that call launched none.  Reading after a series of calls keeps the event queries out of the calls. */
 int dtl_rx_kernel_ms(dtl_rx* h, int32_t back, double* ldpc_ms, double* payload_ms);
+/* Device time per kernel of the last call made with DTL_RX_WANT_KERNEL_SPLIT, summed over the kernel's launches in that call
+ * (HIP events recorded on the call's stream around each launch): which kernel is the longest is measured, not assumed. */
+enum dtl_rx_kernel_id {
+    DTL_K_SYNC_EDGES = 0, DTL_K_HEADER = 1, DTL_K_FRAME_EQ = 2, DTL_K_DEMAP = 3, DTL_K_LDPC = 4, DTL_K_TB_CHECK = 5, DTL_K_COUNT = 6
+};
+typedef struct dtl_rx_kernel_times {
+    double ms[DTL_K_COUNT];         /* sum over the launches; DEMAP: the soft demapper, or the no-FEC tail kernel */
+    int32_t launches[DTL_K_COUNT];
+    double longest_launch_ms[DTL_K_COUNT];
+} dtl_rx_kernel_times;
+int dtl_rx_kernel_split(dtl_rx* h, dtl_rx_kernel_times* out);
 
 /* ---------------------------------------------------------------------------------------------------
  * Batched transmitter (the frame generator).  Replaces the TX hier block of
@@ -365,6 +378,40 @@ typedef struct dtl_tb_span {
 int dtl_tb_gather(const int32_t* code_n, const int32_t* code_k, int32_t n_codes, int32_t frame_capacity, int32_t max_bps,
                   const dtl_rx_frame_info* frames_host, int64_t n_frames, dtl_cw_desc* d_cw_desc, int64_t cw_cap,
                   int64_t* n_cw, dtl_tb_span* spans_host, int64_t span_cap, int64_t* n_spans, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Frame-batch sharding over the GPUs of one node (host arithmetic only: no device, no communication library).
+ * Frames are independent given their own preamble and header -- the reference resets the equaliser's taps and its SNR
+ * estimator for every frame (lib/dtl/ofdm_adaptive_frame_equalizer_vcvc_impl.cc:117-118,180) -- so one stream of
+ * back-to-back frames is cut into contiguous runs, one per GPU, each decoded by its own receiver handle
+ * (dtl_rx_cfg.device) with a few frames of context on either side; the caller in the reference is the hier block
+ * python/dtl/ofdm_adaptive_rx.py:42-59, which a multi-GPU host instantiates once per device.
+ * ------------------------------------------------------------------------------------------------- */
+/* samples [start, stop) are what the rank decodes; a transport block belongs to the rank whose [own_lo, own_hi) holds
+ * the trigger of the frame it starts in */
+typedef struct dtl_shard {
+    int64_t start, stop, own_lo, own_hi;
+} dtl_shard;
+/* n_frames frames of frame_samples samples follow `lead` samples of lead-in in a stream of total_samples; rank r of
+ * world_size owns frames [floor(F r / G), floor(F (r + 1) / G)).  Decoded range: max(guard_frames, 4) frames in front
+ * (frame_detect_bb must be in sync -- three consistent triggers -- before the rank's own frames begin), guard_frames
+ * behind (a transport block that starts in the rank's last frame must be complete: 3 for blocks of about one frame). */
+int dtl_shard_plan(int64_t n_frames, int64_t frame_samples, int64_t lead, int64_t total_samples, int32_t world_size,
+                   int32_t rank, int32_t guard_frames, dtl_shard* out);
+/* Cut a shard into at most n_pieces consecutive pieces for a pipelined hand-over (receive piece k + 1 while
+ * dtl_rx_process_stream decodes piece k: the streaming call returns the same frames whatever the cuts).  bounds:
+ * n_pieces + 1 entries; piece j is [bounds[j], bounds[j + 1]), *n_out pieces; cuts lie at multiples of `align` samples
+ * behind the shard's start (4096 = the sync kernel's tile). */
+int dtl_shard_pieces(const dtl_shard* plan, int32_t n_pieces, int64_t align, int64_t* bounds, int32_t* n_out);
+/* Indices into `tbs` of the transport blocks this rank owns.  frames / tbs: the records of the rank's decode (one
+ * dtl_rx_process call, or the concatenation over the dtl_rx_process_stream calls of its pieces), trigger positions
+ * relative to plan->start.  *n_out = count; DTL_ERR_CAPACITY when cap is too small. */
+int dtl_owned_blocks(const dtl_rx_frame_info* frames, int64_t n_frames, const dtl_rx_tb_info* tbs, int64_t n_tbs,
+                     const dtl_shard* plan, int64_t* idx_out, int64_t cap, int64_t* n_out);
+/* Byte ranges (offset, length) of the decoded output that hold the CRC-ok blocks among idx[0..n_idx), adjacent blocks
+ * merged -- usually ONE range: what a rank sends to the root. */
+int dtl_owned_payload_ranges(const dtl_rx_tb_info* tbs, int64_t n_tbs, const int64_t* idx, int64_t n_idx, int64_t* offs,
+                             int64_t* lens, int64_t cap, int64_t* n_out);
 
 /* device-to-device copy on `stream` (lets a host binding snapshot result buffers it does not own) */
 int dtl_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream);

@@ -195,3 +195,168 @@ def test_block_ownership_against_ground_truth_with_losses():
         keep = owned_blocks(fr, tb, plan)
         want = np.nonzero(np.array(truth))[0]
         assert np.array_equal(keep, want), (trial, span, keep[:10], want[:10])
+
+
+PIECES_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["DTL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from gr_dtl_amd.sharding import (ShardResult, decode_pieces, gather_results, owned_payload, scatter_pieces, scatter_stream,
+                                 shard_pieces, shard_plan)
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_frames, fs, lead = 61, 7680, 100
+total = lead + n_frames * fs + fs
+g = torch.Generator().manual_seed(9)
+full = torch.view_as_complex(torch.randn((total, 2), generator=g))
+x = full.clone() if rank == 0 else None
+# one-shot and pipelined hand-over deliver the same samples; the pieces tile the rank's block, cut at tile multiples
+whole, plan = scatter_stream(x, n_frames, fs, lead, total, dist)
+for n_pieces in (1, 3, 8):
+    feed = scatter_pieces(x, n_frames, fs, lead, total, dist, n_pieces=n_pieces)
+    assert feed.plan == plan == shard_plan(n_frames, fs, lead, total, world, rank)
+    assert feed.bounds == shard_pieces(plan, n_pieces) and len(feed) == n_pieces
+    assert feed.bounds[0] == plan["start"] and feed.bounds[-1] == plan["stop"]
+    assert all((b - plan["start"]) % 4096 == 0 for b in feed.bounds[1:-1])
+    got = list(feed)
+    feed.finish()
+    assert all(p.dtype == torch.complex64 for p in got)
+    assert torch.equal(torch.cat(got), whole) and torch.equal(whole, full[plan["start"]:plan["stop"]])
+
+# decode_pieces with a stand-in receiver whose "frames" are the positions of a marker value in the stream: the merged
+# records of the streamed calls must be what one call over the whole block reports
+class FakeResult:
+    def __init__(self, frames, tbs, payload):
+        self.frames, self.tbs, self.payload, self.n_payload_frames = frames, tbs, payload, len(frames)
+FDT = np.dtype([("trigger", "<i8"), ("payload_index", "<i4"), ("payload_len", "<i4"), ("tb_no", "<i4")])
+TDT = np.dtype([("tb_no", "<i4"), ("crc_ok", "<i4"), ("user_bits", "<i4"), ("out_offset", "<i8")])
+class FakeRx:
+    """a frame starts every `fs` samples behind `lead` of the ORIGINAL stream; block number = frame index mod 256"""
+    def __init__(self, start): self.start, self.pos = start, 0
+    def reset(self): self.pos = 0
+    def feed(self, piece, final=False):
+        lo, hi = self.pos, self.pos + piece.numel()
+        self.pos = hi
+        first = -(-(self.start + lo - lead) // fs)                 # frames whose first sample lies in [lo, hi)
+        idx = [f for f in range(max(first, 0), n_frames) if self.start + lo <= lead + f * fs < self.start + hi]
+        fr = np.zeros(len(idx), FDT)
+        tb = np.zeros(len(idx), TDT)
+        for i, f in enumerate(idx):
+            fr[i] = (lead + f * fs - self.start, i, 10, f % 256)
+            tb[i] = (f % 256, 1, 24, 3 * i)
+        pay = torch.tensor([b for f in idx for b in (f % 251, (f * 7) % 251, 255)], dtype=torch.uint8)
+        return FakeResult(fr, tb, pay)
+feed = scatter_pieces(x, n_frames, fs, lead, total, dist, n_pieces=5)
+res = decode_pieces(FakeRx(plan["start"]), feed)
+feed.finish()
+one = FakeRx(plan["start"]); one.reset()
+ref = one.feed(whole, final=True)
+assert np.array_equal(res.frames["trigger"], ref.frames["trigger"]) and np.array_equal(res.tbs["tb_no"], ref.tbs["tb_no"])
+assert np.array_equal(res.tbs["out_offset"], ref.tbs["out_offset"]) and torch.equal(res.payload, ref.payload)
+data, mine = owned_payload(res, plan)
+gp, gr = gather_results(data, mine, dist)
+if rank == 0:
+    want = np.array([b for f in range(n_frames) for b in (f % 251, (f * 7) % 251, 255)], dtype=np.uint8)
+    assert np.array_equal(gp, want), (gp.size, want.size)
+    assert list(gr["tb_no"]) == [f % 256 for f in range(n_frames)]
+    print("PIECES OK", world, gp.size)
+dist.destroy_process_group()
+'''
+
+
+def _launch(tmp_path, text, world, name):
+    script = tmp_path / name
+    script.write_text(text)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DTL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_pipelined_scatter_two_and_three_ranks(tmp_path, dtl):
+    """scatter_pieces (the hand-over that overlaps with the decode) == scatter_stream, sample for sample, with 1 / 3 / 8
+    pieces; the records of a block decoded piece by piece merge into those of one call; ownership + gather reassemble the
+    stream's blocks exactly once -- gloo, world size 2 and 3."""
+    for world in (2, 3):
+        out = _launch(tmp_path, PIECES_WORKER, world, "worker_pieces.py")
+        assert out.returncode == 0, out.stderr[-3000:]
+        assert "PIECES OK %d 183" % world in out.stdout
+
+
+def test_c_abi_sharding_equals_the_numpy_restatement(dtl):
+    """dtl_shard_plan / dtl_owned_blocks / dtl_owned_payload_ranges (what a C++ host calls) against an independent numpy
+    statement of the same rules, on random shapes."""
+    import numpy as np
+    from gr_dtl_amd.sharding import owned_blocks, owned_payload, shard_pieces, shard_plan
+
+    def np_plan(n_frames, fs, lead, total, world, rank, guard=3):
+        lo, hi = (n_frames * rank) // world, (n_frames * (rank + 1)) // world
+        own_lo = lead + lo * fs if rank else 0
+        own_hi = lead + hi * fs if rank + 1 < world else total
+        start = max(0, own_lo - max(guard, 4) * fs) if rank else 0
+        stop = min(total, own_hi + guard * fs) if rank + 1 < world else total
+        return dict(start=start, stop=stop, own_lo=min(own_lo, total), own_hi=min(own_hi, total))
+
+    def np_unwrap(v):
+        v = np.asarray(v, dtype=np.int64)
+        return v if v.size == 0 else np.concatenate([[0], np.cumsum(np.diff(v) % 256)])
+
+    def np_owned(frames, tbs, plan):
+        m = (frames["payload_index"] >= 0) & (frames["payload_len"] > 0)
+        f_no, f_pos = frames["tb_no"][m].astype(np.int64), frames["trigger"][m].astype(np.int64) + plan["start"]
+        if f_no.size == 0 or len(tbs) == 0:
+            return np.zeros(0, np.int64)
+        first = np.concatenate([[True], f_no[1:] != f_no[:-1]])
+        s_no, s_pos = f_no[first], f_pos[first]
+        s_seq = np_unwrap(s_no)
+        t_no = tbs["tb_no"].astype(np.int64)
+        t_seq = np_unwrap(t_no) + (t_no[0] - s_no[0]) % 256
+        at = np.searchsorted(s_seq, t_seq)
+        hit = (at < s_seq.size) & (s_seq[np.minimum(at, s_seq.size - 1)] == t_seq)
+        pos = np.where(hit, s_pos[np.minimum(at, s_seq.size - 1)], -1)
+        idx = np.maximum.accumulate(np.where(hit, np.arange(len(tbs)), -1))
+        pos = np.where(idx >= 0, pos[np.maximum(idx, 0)], -1)
+        return np.nonzero((pos >= plan["own_lo"]) & (pos < plan["own_hi"]))[0].astype(np.int64)
+
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        n_frames, fs, lead = int(rng.integers(0, 5000)), int(rng.choice([1920, 7680, 17920])), int(rng.integers(0, 300))
+        total = lead + n_frames * fs + int(rng.integers(0, 2 * fs))
+        world = int(rng.integers(1, 9))
+        guard = int(rng.choice([1, 3, 5]))
+        for rank in range(world):
+            p = shard_plan(n_frames, fs, lead, total, world, rank, guard)
+            assert p == np_plan(n_frames, fs, lead, total, world, rank, guard)
+            b = shard_pieces(p, int(rng.integers(1, 12)))
+            assert b[0] == p["start"] and b[-1] == p["stop"] and all(x < y for x, y in zip(b, b[1:])) or p["stop"] == p["start"]
+    fdt = np.dtype([("trigger", "<i8"), ("payload_index", "<i4"), ("payload_len", "<i4"), ("tb_no", "<i4")])
+    tdt = np.dtype([("tb_no", "<i4"), ("crc_ok", "<i4"), ("user_bits", "<i4"), ("out_offset", "<i8")])
+    for _ in range(300):
+        nf = int(rng.integers(0, 400))
+        fr = np.zeros(nf, fdt)
+        fr["trigger"] = np.sort(rng.integers(0, 10 ** 6, nf))
+        fr["payload_index"] = np.where(rng.random(nf) < 0.1, -1, 1)
+        fr["payload_len"] = np.where(rng.random(nf) < 0.05, 0, 100)
+        fr["tb_no"] = (int(rng.integers(0, 256)) + np.cumsum(rng.integers(0, 3, nf))) % 256
+        nt = int(rng.integers(0, 300))
+        tb = np.zeros(nt, tdt)
+        tb["tb_no"] = (int(rng.integers(0, 256)) + np.cumsum(rng.integers(0, 3, nt))) % 256
+        tb["crc_ok"] = rng.random(nt) < 0.8
+        tb["user_bits"] = 8 * rng.integers(1, 40, nt)
+        off = np.concatenate([[0], np.cumsum(np.where(tb["crc_ok"] == 1, tb["user_bits"] // 8, 0))[:-1]]) if nt else np.zeros(0)
+        tb["out_offset"] = np.where(tb["crc_ok"] == 1, off, -1)
+        lo = int(rng.integers(0, 10 ** 6))
+        plan = dict(start=int(rng.integers(0, 1000)), stop=10 ** 7, own_lo=lo, own_hi=lo + int(rng.integers(1, 10 ** 6)))
+        keep = owned_blocks(fr, tb, plan)
+        assert np.array_equal(keep, np_owned(fr, tb, plan))
+
+        class R:
+            frames, tbs, payload = fr, tb, np.arange(int(np.where(tb["crc_ok"] == 1, tb["user_bits"] // 8, 0).sum()) if nt else 0, dtype=np.int64).astype(np.uint8)
+        data, mine = owned_payload(R, plan)
+        ok = mine[mine["crc_ok"] == 1]
+        want = np.concatenate([R.payload[int(o):int(o + n // 8)] for o, n in zip(ok["out_offset"], ok["user_bits"])] or [R.payload[:0]])
+        assert np.array_equal(data, want)
