@@ -333,6 +333,52 @@ def workload_record(dtl, name, device, steps, barrier, arith, seed):
     return rec
 
 
+def host_fed_run(rx, host, sl, bufs, copy_stream, out_host=None, timeline=None, out_stream=None):
+    """The host-fed loop: slice k+1 goes host -> device on `copy_stream` (into the buffer feed(k-1) has finished with) while
+    feed(k) decodes; decoded bytes return to pinned host memory.  timeline: a list that receives one row per slice
+    (copy start / end on the copy stream in ms since the first copy, feed() wall interval in ms) -- tools/host_fed_probe.py."""
+    import torch
+    ev0 = [torch.cuda.Event(enable_timing=timeline is not None) for _ in sl]
+    ev1 = [torch.cuda.Event(enable_timing=timeline is not None) for _ in sl]
+
+    def enqueue(k):
+        a, b = sl[k]
+        with torch.cuda.stream(copy_stream):
+            if timeline is not None:
+                ev0[k].record(copy_stream)
+            bufs[k % 2][:b - a].copy_(host[a:b], non_blocking=True)
+            ev1[k].record(copy_stream)
+    t_base = time.perf_counter()
+    enqueue(0)
+    at, walls = 0, []
+    for k, (a, b) in enumerate(sl):
+        if k + 1 < len(sl):            # slice k+1 into the other buffer: feed(k-1), its last reader, has returned
+            enqueue(k + 1)
+        torch.cuda.current_stream().wait_event(ev1[k])
+        t0 = time.perf_counter()
+        res = rx.feed(bufs[k % 2][:b - a], final=(k + 1 == len(sl)))
+        walls.append((t0 - t_base, time.perf_counter() - t_base, list(res.stage_ms[:6])))
+        m = int(res.payload.numel())
+        if m and out_host is not None:
+            # The bytes go home on a stream of their own.  On the decode stream this device-to-host copy (a DMA transfer, like
+            # the big host-to-device copy in flight, and queued behind it by the copy engine) would hold up the NEXT call's
+            # kernels until the slice in flight has landed: measured, every call then waits one whole slice (40 instead of
+            # 55 GB/s).  Off the decode stream it still waits its turn, but nothing waits for it.
+            if out_stream is not None:
+                out_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(out_stream):
+                    out_host[at:at + m].copy_(res.payload, non_blocking=True)
+                res.payload.record_stream(out_stream)
+            else:
+                out_host[at:at + m].copy_(res.payload, non_blocking=True)
+        at += m
+    torch.cuda.synchronize()
+    if timeline is not None:
+        for k in range(len(sl)):
+            timeline.append((ev0[0].elapsed_time(ev0[k]), ev0[0].elapsed_time(ev1[k]), walls[k][0] * 1e3, walls[k][1] * 1e3, walls[k][2]))
+    return at
+
+
 def host_fed_record(dtl, rx, x, n_slices=16):
     """Host buffers in, host buffers out (the deployment of python/dtl/ofdm_receiver.py:59-246: the hier block's ports are
     host ring buffers): the stream sits in page-locked HOST memory and reaches the device slice by slice, the copy of
@@ -343,7 +389,8 @@ def host_fed_record(dtl, rx, x, n_slices=16):
     dev = x.device
     n = x.numel()
     ref = rx.work(x)
-    want = ref.payload.clone()
+    want = ref.payload.cpu()
+    del ref
     host = torch.empty(n, dtype=torch.complex64, pin_memory=True)
     host.copy_(x)
     cuts = [(n * k // n_slices) & ~4095 for k in range(n_slices)] + [n]
@@ -351,43 +398,29 @@ def host_fed_record(dtl, rx, x, n_slices=16):
     biggest = max(b - a for a, b in sl)
     bufs = [torch.empty(biggest, dtype=torch.complex64, device=dev) for _ in range(2)]
     out_host = torch.empty(max(int(want.numel()), 1), dtype=torch.uint8, pin_memory=True)
-    copy_stream = torch.cuda.Stream(device=dev)
-    ev = [torch.cuda.Event() for _ in range(2)]
+    copy_stream, out_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
-    # (a) the link alone: the same slices, copies only
-    t0 = time.perf_counter()
-    with torch.cuda.stream(copy_stream):
-        for k, (a, b) in enumerate(sl):
-            bufs[k % 2][:b - a].copy_(host[a:b], non_blocking=True)
-    copy_stream.synchronize()
-    t_link = time.perf_counter() - t0
-
-    def run():
-        got, at = [], 0
+    # (a) the link alone: the same slices, copies only (best of two passes)
+    t_link = None
+    for _ in range(2):
+        t0 = time.perf_counter()
         with torch.cuda.stream(copy_stream):
-            bufs[0][:sl[0][1] - sl[0][0]].copy_(host[sl[0][0]:sl[0][1]], non_blocking=True)
-            ev[0].record(copy_stream)
-        for k, (a, b) in enumerate(sl):
-            if k + 1 < len(sl):        # slice k+1 into the other buffer: feed(k-1), its last reader, has returned
-                a2, b2 = sl[k + 1]
-                with torch.cuda.stream(copy_stream):
-                    bufs[(k + 1) % 2][:b2 - a2].copy_(host[a2:b2], non_blocking=True)
-                    ev[(k + 1) % 2].record(copy_stream)
-            torch.cuda.current_stream().wait_event(ev[k % 2])
-            res = rx.feed(bufs[k % 2][:b - a], final=(k + 1 == len(sl)))
-            m = int(res.payload.numel())
-            if m:
-                out_host[at:at + m].copy_(res.payload, non_blocking=True)
-                at += m
-        torch.cuda.synchronize()
-        return at
+            for k, (a, b) in enumerate(sl):
+                bufs[k % 2][:b - a].copy_(host[a:b], non_blocking=True)
+        copy_stream.synchronize()
+        dt = time.perf_counter() - t0
+        t_link = dt if t_link is None else min(t_link, dt)
+    # (b) copies under the decode
     rx.reset()
-    run()                                                   # warm-up (buffers of the streamed path)
-    rx.reset()
-    t0 = time.perf_counter()
-    n_out = run()
-    t_fed = time.perf_counter() - t0
-    same = n_out == int(want.numel()) and bool(torch.equal(out_host[:n_out], want.cpu()))
+    host_fed_run(rx, host, sl, bufs, copy_stream, out_host, out_stream=out_stream)        # warm-up (buffers of the streamed path)
+    t_fed, n_out = None, 0
+    for _ in range(2):
+        rx.reset()
+        t0 = time.perf_counter()
+        n_out = host_fed_run(rx, host, sl, bufs, copy_stream, out_host, out_stream=out_stream)
+        dt = time.perf_counter() - t0
+        t_fed = dt if t_fed is None else min(t_fed, dt)
+    same = n_out == int(want.numel()) and bool(torch.equal(out_host[:n_out], want))
     link = n * 8 / t_link / 1e9
     return {"slices": len(sl), "samples": int(n), "ms": round(t_fed * 1e3, 3), "msamples_per_s": round(n / t_fed / 1e6, 1),
             "GBps": round(n * 8 / t_fed / 1e9, 2), "link_GBps_copies_alone": round(link, 2),

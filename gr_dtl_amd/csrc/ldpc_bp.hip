@@ -27,9 +27,7 @@
 
 #pragma clang fp contract(off)
 
-#ifndef DTL_ABLATE
-#define DTL_ABLATE 0 // timing experiments only (tools/ablate_ldpc.sh): 21 no syndrome check, 22 no output stage, 23 no soft-bit loads
-#endif
+#include "dtl_ablate.h"   // timing experiments: every `ablated(k)` below is false in the shipped library
 
 namespace dtl {
 
@@ -172,6 +170,7 @@ constexpr int kNpWaves = 16;
 constexpr int kNpChunk = 16;  // codewords per queue ticket (large batches)
 constexpr int kNpQueues = 8;       // ticket counters per launch ...
 constexpr int kNpQueueStride = 16; // ... this many 32-bit words apart (one 64-byte line each)
+constexpr int kNpSplitIterations = 3; // decisions-first variable passes (exact arithmetic): measured, tools/ldpc_probe.py
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                                                                      int max_it, float sigma,
                                                                      uint8_t* __restrict__ out_bits,
                                                                      int32_t* __restrict__ out_nit,
-                                                                     unsigned int* __restrict__ queue, int chunk, int packed)
+                                                                     unsigned int* __restrict__ queue, int chunk, int packed, int split_iterations)
 {
     static_assert(MAXC <= 4, "a variable's slot indices are read as one 64-bit word");
     extern __shared__ unsigned char np_smem[];
@@ -310,9 +309,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     // 64-bit reads of a pass fall on distinct banks), and the syndrome bit of a check is the parity of the AND of the
     // two -- no per-variable lookups.
     auto syndrome_ok = [&](const unsigned long long (&X)[NV]) -> bool {
-#if DTL_ABLATE == 21
-        return __ballot(X[0] == 0xdeadbeefull) == 0ull;
-#endif
+        if constexpr (ablated(21)) return __ballot(X[0] == 0xdeadbeefull) == 0ull;
         // (a pass of 64 checks at a time, left at the first pass that holds an unsatisfied check: while a codeword has not
         // converged that is nearly always the first one)
         for (int c0 = 0; c0 < t.m; c0 += kWave) {
@@ -356,11 +353,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         for (int p = 0; p < NV; p++) {
             const unsigned i = min(unsigned(lane + p * kWave), last);
             const uint32_t at = m.off0 + i + (i < len0 ? 0u : hop);
-#if DTL_ABLATE == 23
-            raw[p] = __uint_as_float(at | 0x80000000u);
-#else
-            raw[p] = llr[size_t(at)];
-#endif
+            raw[p] = ablated(23) ? __uint_as_float(at | 0x80000000u) : llr[size_t(at)];
         }
     };
     auto settle = [&](const Meta& m, const float (&raw)[NV], float (&vals)[NV]) {
@@ -424,6 +417,8 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     auto check_phase = [&](auto first, auto tame) {
         constexpr bool FIRST = decltype(first)::value;
         constexpr bool TAME = decltype(tame)::value;
+        // FIRST: the slots hold the factors t = 2/(1+Q) - 1 themselves (see the channel pass: Q_e of the first iteration is
+        // the channel ratio of the edge's VARIABLE, so the factor is formed once per variable, not once per edge)
         // ---- update_chks: lane == check node.  When the last pass would fill at most half of the wave
         // (148 checks = 64 + 64 + 20), it runs with TWO lanes per check instead, each owning half of the
         // row: half the divisions per lane, and the row product is still formed in the reference's
@@ -436,7 +431,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                 double* row = msg + c;                    // message j of check c: row[j * t.m] (see the layout note)
                 double tt[MAXR];
 #pragma unroll
-                for (int j = 0; j < MAXR; j++) tt[j] = div_exact<TAME>(2.0, 1 + (FIRST ? rx[chk_var[c * MAXR + j]] : row[j * t.m])) - 1;
+                for (int j = 0; j < MAXR; j++) tt[j] = FIRST ? row[j * t.m] : div_exact<TAME>(2.0, 1 + row[j * t.m]) - 1;
                 double product = 1.0;
 #pragma unroll
                 for (int j = 0; j < MAXR; j++) product = product * tt[j];
@@ -457,8 +452,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
             double* row = msg + (valid ? c : 0) + (upper ? HR : 0) * t.m;
             double tt[HR];
 #pragma unroll
-            for (int j = 0; j < HR; j++)
-                tt[j] = div_exact<TAME>(2.0, 1 + (FIRST ? rx[chk_var[(valid ? c : 0) * MAXR + (upper ? HR : 0) + j]] : row[j * t.m])) - 1;
+            for (int j = 0; j < HR; j++) tt[j] = FIRST ? row[j * t.m] : div_exact<TAME>(2.0, 1 + row[j * t.m]) - 1;
             double part = 1.0;
 #pragma unroll
             for (int j = 0; j < HR; j++) part = part * tt[j];             // even lane: ((1 t0) t1) t2
@@ -572,11 +566,8 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     settle(m0, nxt, cur);
     while (cw < ncw) {
         const int cw2 = cw1 < ncw ? advance() : ncw;     // (a new ticket: an atomic, waited for before anything else goes out)
-#if DTL_ABLATE == 22
-        if (prev_cw >= 0 && lane == 0) out_nit[prev_cw] = prev_nit;
-#else
-        if (prev_cw >= 0) emit();
-#endif
+        if constexpr (ablated(22)) { if (prev_cw >= 0 && lane == 0) out_nit[prev_cw] = prev_nit; }
+        else if (prev_cw >= 0) emit();
         if (cw1 < ncw) fetch(m1, nxt);
         if (cw2 < ncw) load_meta(cw2, m2);
         const uint32_t out_off = m0.out_off;
@@ -602,15 +593,32 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                 // into a median instruction whose NaN result differs
                 if (FAST) arg = arg > kFastLlrMax ? kFastLlrMax : (arg >= -kFastLlrMax ? arg : -kFastLlrMax);
                 if (v < t.n) {
-                    wild |= !(fabsf(arg) <= kTameArgMax);
-                    rx[v] = dm_exp64(double(arg));
+                    if constexpr (!ablated(25)) wild |= !(fabsf(arg) <= kTameArgMax);
+                    const double lr = ablated(24) ? 1.0 + double(arg) : dm_exp64(double(arg));
+                    rx[v] = lr;
+                    if constexpr (!FAST) {
+                        // spa_initialize + the first half of the first update_chks: Q_e = channel ratio of the edge's variable
+                        // for every edge e of v, so t_e = 2/(1+Q_e) - 1 is ONE value per variable -- formed here once (the
+                        // same IEEE operations on the same operands as the per-edge form: same bits) and written to the
+                        // variable's message slots, where the first check pass finds it: 300 divisions instead of 888
+                        const double tv = 2.0 / (1 + lr) - 1;
+                        const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
+                        unsigned char* msg_b = reinterpret_cast<unsigned char*>(msg);
+#pragma unroll
+                        for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + int((packed >> (16 * i)) & 0xFFFFull)) = tv;
+                    }
                 }
+            }
+            if constexpr (!FAST && !ROWS_FULL) {
+                // a padded row slot (rows lighter than MAXR) belongs to no variable: its factor is exactly 1
+                for (int c = lane; c < t.m; c += kWave)
+                    for (int j = int(chk_deg[c]); j < MAXR; j++) msg[j * t.m + c] = 1.0;
             }
             if (lane == 0) rx[t.n] = 0.0;
             wave_sync();
-            // spa_initialize (Q_e = channel LR of the edge's variable) is folded into the first check pass, which reads
-            // rx through the row's variable indices instead of the message slots
-            if (lane == 0) msg[kOneSlot] = 1.0;
+            // (fast arithmetic: spa_initialize is folded into the first check pass, which reads rx through the row's
+            // variable indices instead of the message slots)
+            if (lane == 0) msg[kOneSlot] = 1.0;   // (a padded column entry named this slot: written above, put right here)
             wave_sync();
             auto iterate = [&](auto tame) {
                 constexpr bool TAME = decltype(tame)::value;
@@ -629,54 +637,80 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                     // lane's reads of a pass precede its writes (one wave, program order), and the slot is set back to
                     // 1.0 behind the writes of each pass (one uniform store instead of a compare + select per entry)
                     unsigned char* msg_b = reinterpret_cast<unsigned char*>(msg);
-                    // (unrolled over the NV passes: the decisions of pass p are the compare's own result, word X[p])
+                    // The variable-to-check messages Q = sum / R of an iteration are read by the NEXT iteration only.  When
+                    // the decisions of this iteration already satisfy every check -- or the iteration limit is reached -- they
+                    // are never read: the exact arithmetic therefore forms the column products and the decisions first
+                    // (DECIDE), runs the syndrome check, and divides only if the codeword goes on (DIVIDE: the products
+                    // are formed again from the same operands -- 3 LDS reads and 3 multiplications per variable against 3
+                    // divisions saved on a codeword's last iteration).  Codewords that have not converged after
+                    // `split_iterations` iterations rarely stop at the next one: from there on the two halves run fused, as one
+                    // pass (no second read), except in the last allowed iteration.  Every message that IS read is the
+                    // reference's: same operations, same operands, same order.
+                    const bool last_allowed = nit == max_it;
+                    auto var_pass = [&](auto decide, auto divide) {
+                        constexpr bool DECIDE = decltype(decide)::value, DIVIDE = decltype(divide)::value;
+                        // (unrolled over the NV passes: the decisions of pass p are the compare's own result, word X[p])
 #pragma unroll
-                    for (int p = 0; p < NV; p++) {
-                        const int v = lane + p * kWave;
-                        bool one = false;
-                        if (v < t.n) {
-                        const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
-                        int ee[MAXC];
-                        double rr[MAXC];
-                        if (FAST) {
-                            // Q_i = (rx R_0 .. R_{i-1}) (R_{i+1} .. R_{d-1}): prefix x suffix, no division
-                            double pre[MAXC + 1], suf[MAXC];
-                            pre[0] = rx[v];
+                        for (int p = 0; p < NV; p++) {
+                            const int v = lane + p * kWave;
+                            bool one = false;
+                            if (v < t.n) {
+                                const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(var_edge + v * 4);
+                                int ee[MAXC];
+                                double rr[MAXC];
+                                if (FAST) {
+                                    // Q_i = (rx R_0 .. R_{i-1}) (R_{i+1} .. R_{d-1}): prefix x suffix, no division
+                                    double pre[MAXC + 1], suf[MAXC];
+                                    pre[0] = rx[v];
 #pragma unroll
-                            for (int i = 0; i < MAXC; i++) {
-                                ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
-                                rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
-                                pre[i + 1] = pre[i] * rr[i];
+                                    for (int i = 0; i < MAXC; i++) {
+                                        ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
+                                        rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
+                                        pre[i + 1] = pre[i] * rr[i];
+                                    }
+                                    if constexpr (DIVIDE) {
+                                        suf[MAXC - 1] = 1.0;
+#pragma unroll
+                                        for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
+#pragma unroll
+                                        for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = pre[i] * suf[i];
+                                    }
+                                    one = pre[MAXC] > 1;
+                                } else {
+                                    double sum = rx[v];
+#pragma unroll
+                                    for (int i = 0; i < MAXC; i++) {
+                                        ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
+                                        rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
+                                        sum = sum * rr[i];
+                                    }
+                                    if constexpr (DIVIDE) {
+#pragma unroll
+                                        for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = div_exact<TAME>(sum, rr[i]);
+                                    }
+                                    one = sum > 1;
+                                }
+                                if constexpr (DIVIDE) msg[kOneSlot] = 1.0;
                             }
-                            suf[MAXC - 1] = 1.0;
-#pragma unroll
-                            for (int i = MAXC - 2; i >= 0; i--) suf[i] = suf[i + 1] * rr[i + 1];
-#pragma unroll
-                            for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = pre[i] * suf[i];
-                            one = pre[MAXC] > 1;
-                        } else {
-                            double sum = rx[v];
-#pragma unroll
-                            for (int i = 0; i < MAXC; i++) {
-                                ee[i] = int((packed >> (16 * i)) & 0xFFFFull);
-                                rr[i] = *reinterpret_cast<const double*>(msg_b + ee[i]);
-                                sum = sum * rr[i];
-                            }
-#pragma unroll
-                            for (int i = 0; i < MAXC; i++) *reinterpret_cast<double*>(msg_b + ee[i]) = div_exact<TAME>(sum, rr[i]);
-                            one = sum > 1;
+                            if constexpr (DECIDE) X[p] = __ballot(one);
                         }
-                        msg[kOneSlot] = 1.0;
-                        }
-                        X[p] = __ballot(one);
+                    };
+                    if (last_allowed || (!FAST && nit <= split_iterations)) {
+                        var_pass(std::true_type{}, std::false_type{});
+                        if (syndrome_ok(X) || last_allowed) break;    // (the check reads the decision words and the row masks only)
+                        var_pass(std::false_type{}, std::true_type{});
+                        wave_sync();
+                    } else {
+                        var_pass(std::true_type{}, std::true_type{});
+                        wave_sync();
+                        if (syndrome_ok(X)) break;
                     }
-                    wave_sync();
-                    if (syndrome_ok(X)) break;
                 }
             };
             // exact arithmetic: the cheaper division form when every channel exponent of this codeword is tame (see
             // div_exact); the choice is wave-uniform.  The fast arithmetic has no per-edge divisions to save.
-            if (FAST || __ballot(wild) != 0ull) iterate(std::false_type{});
+            if constexpr (ablated(26)) { /* no iteration: what a codeword costs that fails its first syndrome check, without them */ }
+            else if (FAST || __ballot(wild) != 0ull) iterate(std::false_type{});
             else iterate(std::true_type{});
         }
         // cldpc::get_systematic_bits: data bit i is variable permute[rank + i], i.e. on-air position rank + i -- the
@@ -843,15 +877,18 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
         // Large batches take 16 codewords per ticket (keeps the same-address atomics off the critical
         // path); small ones shrink the ticket so that all 4096 waves get work and the tail stays short (at 25 k
         // codewords, C2, two per ticket measured 0.36 ms against 0.44 ms for one or four).
-        // (DTL_LDPC_CHUNK: tuning experiments, tools/ablate_ldpc.sh)
+        // (DTL_LDPC_CHUNK: tuning experiments, tools/ldpc_probe.py)
         static const int chunk_cap = [] { const char* e = std::getenv("DTL_LDPC_CHUNK"); return e ? std::max(1, atoi(e)) : kNpChunk; }();
         const int chunk = int(std::max<size_t>(1, std::min<size_t>(size_t(chunk_cap), ncw / (size_t(grid) * kNpWaves * 3))));
         // every launch takes its own ticket counter from a ring: two decodes of one decoder on different streams
         // (legal: decode() is const and takes the caller's stream) never share one
         unsigned int* queue = np_queue_ + size_t(np_launch_.fetch_add(1, std::memory_order_relaxed) % kNpQueueRing) * kNpQueues * kNpQueueStride;
         DTL_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned int) * kNpQueues * kNpQueueStride, stream));
+        // iterations whose variable pass forms the decisions first and divides only if the codeword goes on (see the kernel);
+        // (DTL_LDPC_SPLIT_IT: tuning experiments)
+        static const int split_it = [] { const char* e = std::getenv("DTL_LDPC_SPLIT_IT"); return e ? atoi(e) : kNpSplitIterations; }();
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_chk_var_, np_var_edge_, np_chk_deg_, np_chk_bits_,
-                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk, packed ? 1 : 0);
+                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk, packed ? 1 : 0, split_it);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
     }

@@ -11,11 +11,8 @@
 // FMA contraction, i.e. exactly what libgcc's __divsc3/__mulsc3 give the reference's
 // std::complex<float> code on x86-64.
 #include "rx_kernels.h"
-#ifndef DTL_ABLATE
-#define DTL_ABLATE 0 // timing experiments only (tools/ablate.sh): 1 no derotation, 2 no butterflies, 3 no equaliser;
-                     // demapper: 31 no exponentials, 32 no logarithms, 33 no stores, 34 no symbol loads
-#endif
 
+#include "dtl_ablate.h"   // timing experiments: every `ablated(k)` below is false in the shipped library
 #include "dtl_math.h"
 
 #include <algorithm>
@@ -119,7 +116,7 @@ __device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, 
 // separate passes -- bit-identical), so the N/4 groups of four symbols keep all N lanes busy with half the
 // LDS traffic and half the barriers.  An odd last stage runs as a plain pass.  tw: the N per-pass twiddles in LDS;
 // rows are stored LDS-swizzled (fft_lds_swizzle, rx_types.h): readers index them through it.
-template <int ABL = 0> // timing experiments: see DTL_ABLATE
+template <int ABL = 0> // timing experiments (dtl_ablate.h): 1 / 42 no derotation, 2 / 43 no butterflies
 __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __restrict__ iq, int64_t n_samples,
                                               int64_t trigger, int sym0, int n_sym, const CfoSegment* segs,
                                               int n_segs, const SegWindow& seg, cf32* buf, const cf32* tw)
@@ -165,7 +162,7 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int sidx = q + j * (N >> 2);
-                x[br[j]] = ABL == 1 ? v[j] : cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
+                x[br[j]] = (ABL == 1 || ABL == 42) ? v[j] : cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
             }
         }
     } else {
@@ -182,13 +179,13 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
         for (int uu = 0; uu < 4; uu++) {
             if (uu < n_sym) {
                 const int64_t i = trigger + int64_t(sym0 + uu) * P + t.cp_len + tid;
-                buf[uu * N + br] = cmul(v[uu], expj(osc_phase(segs, n_segs, seg, i, sens)));
+                buf[uu * N + br] = (ABL == 1 || ABL == 42) ? v[uu] : cmul(v[uu], expj(osc_phase(segs, n_segs, seg, i, sens)));
             }
         }
     }
     sync_stage();
     int st = 0;
-    if (ABL == 2) st = logN;
+    if (ABL == 2 || ABL == 43) st = logN;
     for (; st + 1 < logN; st += 2) {
         if (active) {
             const int h = 1 << st;
@@ -386,13 +383,13 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         const cf32* rb = raw + sync_pad<R>(base - half);
 #pragma unroll
         for (int s = 0; s < R; s++) {
-#if DTL_ABLATE != 12   // timing experiments: 12 = no pass A either (staging, barriers and scans only)
-            const cf32 a = ra[s], b = rb[s];
-            const float c_re = a.re * b.re + a.im * b.im;
-            const float c_im = a.im * b.re - a.re * b.im;
-            const float e = 0.5f * (a.re * a.re + a.im * a.im);
-            tr += double(c_re); ti += double(c_im); te += double(e);
-#endif
+            if constexpr (!ablated(12)) {
+                const cf32 a = ra[s], b = rb[s];
+                const float c_re = a.re * b.re + a.im * b.im;
+                const float c_im = a.im * b.re - a.re * b.im;
+                const float e = 0.5f * (a.re * a.re + a.im * a.im);
+                tr += double(c_re); ti += double(c_im); te += double(e);
+            }
         }
     }
     double hr = 0, hi = 0, he = 0; // history strip `tid` (wave 0 only: nh <= 64)
@@ -511,11 +508,10 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
     // one wave instead of one pass of every wave that holds one.  dtl_sync_pretest_check /
     // tests/test_sync_pretest_gpu.py run both tests on every strip of ordinary and adversarial streams: 0 disagreements.
     unsigned flags = 0;
-#if DTL_ABLATE == 11 || DTL_ABLATE == 12   // timing experiments: no pass C at all
-    sflags[tid] = 0;
-    __syncthreads();
-#else
-    if constexpr (PRE && !WITH_METRIC) {
+    if constexpr (ablated(11) || ablated(12)) {
+        sflags[tid] = 0;
+        __syncthreads();
+    } else if constexpr (PRE && !WITH_METRIC) {
         const int k = nh + tid;                     // this strip
         double Wr, Wi, We;
         window_before(tid, Wr, Wi, We);
@@ -557,7 +553,6 @@ __global__ __launch_bounds__(kSyncTile / R) __attribute__((amdgpu_waves_per_eu(R
         sflags[tid] = (unsigned short)exact_strip(tid);
         __syncthreads();
     }
-#endif
     flags = sflags[tid];
     // (a thread that goes on -- m0 < n -- has a complete strip in front of it: its last output is bit R - 1)
     const bool prev = tid ? ((sflags[tid - 1] >> (R - 1)) & 1u) != 0 : prev0;
@@ -615,7 +610,7 @@ template <bool STAGE>
 __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n_samples,
                               const Candidate* __restrict__ cands, const CfoSegment* __restrict__ segs,
                               int n_segs, HeaderRec* __restrict__ recs, cf32* __restrict__ taps_out,
-                              uint8_t* __restrict__ hdr_bits_out, int search_in_lds, HeaderStageIo io)
+                              uint8_t* __restrict__ hdr_bits_out, int search_chunk, HeaderStageIo io)
 {
     extern __shared__ unsigned char smem_raw[];
     const int N = t.fft_len, h = t.header_len, tid = threadIdx.x;
@@ -624,7 +619,9 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
     float* gabs = reinterpret_cast<float*>(H + N);          // N/2+2 |B(g)| values
     uint8_t* bits = reinterpret_cast<uint8_t*>(gabs + N / 2 + 2); // hdr_bits
     cf32* tw = reinterpret_cast<cf32*>(bits + ((t.hdr_bits + 15) & ~15)); // N per-pass twiddles
-    cf32* terms = tw + N;                                // n_g x (n_act + 1) products of the offset search
+    cf32* terms = tw + N;                                // n_g x (search_chunk + 1) products of the offset search
+    cf32* s_cvc = terms + size_t((t.g_max - t.g_min) / 2 + 1) * (search_chunk + 1);   // n_sync_act: conj(corr_v) of the participating carriers
+    uint16_t* s_kact = reinterpret_cast<uint16_t*>(s_cvc + t.n_sync_act);              // n_sync_act: their positions
     __shared__ int s_off;
 
     tw[tid] = t.twiddle[tid];
@@ -641,54 +638,65 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
         const Candidate cd = cands[blockIdx.x];
         const SegWindow sw = seg_window(segs, n_segs, cd.seg);
         for (int s = 0; s < 2 + h; s += 4)
-            load_and_fft4(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, sw, Y + size_t(s) * N, tw);
+            load_and_fft4<(kAblate == 42 || kAblate == 43) ? kAblate : 0>(t, iq, n_samples, cd.trigger, s, min(4, 2 + h - s), segs, n_segs, sw, Y + size_t(s) * N, tw);
     }
     const bool given_taps = STAGE && io.taps_in != nullptr;     // dtl_header_decode: channel estimate supplied
     // shifted view: Ysh(s, k) = Y[s][(k + N/2) % N] (rows are stored swizzled)
     auto ysh = [&](int s, int k) -> cf32 { return Y[size_t(s) * N + fft_lds_swizzle((k + N / 2) & (N - 1))]; };
 
     // get_carr_offset: B(g) = sum_k conj(y1[k+g]) * conj(corr_v[k]) * y2[k+g], first maximum wins.
-    // The reference adds the terms in carrier order in float, so the sum of one offset g is a serial chain;
-    // what can be shared is the work inside it: all lanes form the products (lane == participating carrier,
-    // half of the workgroup per offset parity) and park them in LDS, then one lane per offset only adds.
+    // The reference adds the terms in carrier order in float, so the sum of one offset g is a serial chain; what can be
+    // shared is the work inside it.  Lane g < n_g owns the running sum of offset g (a register, carried over the rounds);
+    // the products are formed by ALL lanes, a chunk of `search_chunk` participating carriers at a time (every offset's
+    // products of the chunk parked in LDS: n_g x (chunk + 1) entries, the odd row stride keeps the adding lanes' 64-bit
+    // reads on distinct banks), then the n_g lanes add their chunk in order.  The chunk is chosen on the host so that the
+    // product table stays small whatever the transform length: a 1024-point header searches 97 offsets over 416 carriers
+    // (323 KB of products -- the form that parked them all fell back to one lane per offset forming its own 1024 products:
+    // 50 us per header, 23 ms per 28 k-frame step).
     const int n_g = (t.g_max - t.g_min) / 2 + 1;
     const int n_act = t.n_sync_act;
     if (given_taps) {
         if (tid == 0) s_off = io.carr_off_in[blockIdx.x];
-    } else if (search_in_lds) {
-        const int per = n_act <= N / 2 ? N / 2 : N;          // lanes reserved per offset
-        const int groups = N / per, grp = tid / per, a = tid - grp * per;
-        // two rounds over half of the offsets each: half the LDS for the products, more workgroups per CU
-        const int rows = (n_g + 1) / 2;
-        for (int g0 = 0; g0 < n_g; g0 += rows) {
-            const int g1 = min(g0 + rows, n_g);
-            if (a < n_act) {
-                const int k = t.sync_act[a];
-                const cf32 cvc = cconj(t.corr_v[k]);
-                for (int gi = g0 + grp; gi < g1; gi += groups) {
-                    const int g = t.g_min + 2 * gi;
-                    terms[(gi - g0) * (n_act + 1) + a] = cmul(cmul(cconj(ysh(0, k + g)), cvc), ysh(1, k + g));
+    } else if (ablated(41)) {
+        if (tid < n_g) gabs[tid] = 0.0f;
+    } else {
+        const int CH = search_chunk, ch_log = __ffs(CH) - 1;          // a power of two
+        for (int a = tid; a < n_act; a += blockDim.x) {               // the participating carriers and conj(corr_v) of each
+            const int k = t.sync_act[a];
+            s_kact[a] = uint16_t(k);
+            s_cvc[a] = cconj(t.corr_v[k]);
+        }
+        __syncthreads();
+        cf32 acc = { 0.0f, 0.0f };
+        for (int a0 = 0; a0 < n_act; a0 += CH) {
+            const int na = min(CH, n_act - a0);
+            for (int p = tid; p < (n_g << ch_log); p += blockDim.x) {
+                const int gi = p >> ch_log, a = p & (CH - 1);
+                if (a < na) {
+                    const int k = s_kact[a0 + a], g = t.g_min + 2 * gi;
+                    terms[gi * (CH + 1) + a] = cmul(cmul(cconj(ysh(0, k + g)), s_cvc[a0 + a]), ysh(1, k + g));
                 }
             }
             __syncthreads();
-            if (tid < g1 - g0) {
-                cf32 acc = { 0.0f, 0.0f };
-                const cf32* row = terms + tid * (n_act + 1);
-                for (int i = 0; i < n_act; i++) acc = cadd(acc, row[i]);
-                gabs[g0 + tid] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+            if (tid < n_g) {
+                // eight terms at a time: the loads go out together (one LDS latency per eight, not per term), the adds follow
+                // in carrier order; a slot behind the chunk's last carrier is read (in bounds: the row has CH + 1 entries)
+                // and not added
+                const cf32* row = terms + tid * (CH + 1);
+                for (int i0 = 0; i0 < na; i0 += 8) {
+                    cf32 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = row[min(i0 + j, CH)];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const cf32 sum = cadd(acc, v[j]);
+                        acc = i0 + j < na ? sum : acc;
+                    }
+                }
             }
             __syncthreads();                                 // the rows are rewritten by the next round
         }
-    } else {
-        for (int gi = tid; gi < n_g; gi += blockDim.x) {
-            const int g = t.g_min + 2 * gi;
-            cf32 acc = { 0.0f, 0.0f };
-            for (int k = 0; k < N; k++) {
-                const cf32 cv = t.corr_v[k];
-                if (cnonzero(cv)) acc = cadd(acc, cmul(cmul(cconj(ysh(0, k + g)), cconj(cv)), ysh(1, k + g)));
-            }
-            gabs[gi] = sqrtf(acc.re * acc.re + acc.im * acc.im);
-        }
+        if (tid < n_g) gabs[tid] = sqrtf(acc.re * acc.re + acc.im * acc.im);
     }
     __syncthreads();
     if (tid == 0 && !given_taps) {
@@ -769,7 +777,7 @@ __global__ void header_kernel(RxTables t, const cf32* __restrict__ iq, int64_t n
         }
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64 && !ablated(44)) {
         // header bit k (k < 128 covers every field and the CRC of both header layouts) as bit k of two ballots
         const int f_bits = t.has_fec ? 80 : 32;
         const unsigned long long w0 = __ballot(tid < HL && (bits[tid < HL ? tid : 0] & 1));
@@ -843,13 +851,8 @@ __device__ __forceinline__ void demap_log_ratios(const float (&p1)[BPS], const f
 #pragma unroll
         for (int j = 0; j < BPS; j++) least = fminf(least, fminf(p1[j], p0[j]));
         if (__all(least >= 1.17549435e-38f)) {
-#if DTL_ABLATE == 32
 #pragma unroll
-            for (int j = 0; j < BPS; j++) o[j] = p1[j] - p0[j];
-#else
-#pragma unroll
-            for (int j = 0; j < BPS; j++) o[j] = dm_log<true>(p1[j]) - dm_log<true>(p0[j]);
-#endif
+            for (int j = 0; j < BPS; j++) o[j] = ablated(32) ? p1[j] - p0[j] : dm_log<true>(p1[j]) - dm_log<true>(p0[j]);
             return;
         }
     }
@@ -940,12 +943,12 @@ __device__ __forceinline__ void soft_demap_symbol(cf32 s, const cf32* __restrict
             dm_f2 dist2[K], d[K];
 #pragma unroll
             for (int i = 0; i < K; i++) dist2[i] = dm_f2{ distance(m0 + 2 * i), distance(m0 + 2 * i + 1) };
-#if DTL_ABLATE == 31
+            if constexpr (ablated(31)) {
 #pragma unroll
-            for (int i = 0; i < K; i++) d[i] = dist2[i] * dm_f2{ rinv, rinv };
-#else
-            dm_exp_neg_div_by_pairs<K>(dist2, npwr, rinv, d);
-#endif
+                for (int i = 0; i < K; i++) d[i] = dist2[i] * dm_f2{ rinv, rinv };
+            } else {
+                dm_exp_neg_div_by_pairs<K>(dist2, npwr, rinv, d);
+            }
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 const int m = m0 + 2 * i;
@@ -1162,11 +1165,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
         // pilots and data carriers run the same arithmetic -- equalise with the current tap, then pull the
         // tap towards y / (known or decided symbol) -- so the two cases share one pair of complex divisions
         // (lanes of one wave hold both kinds; separate branches would execute both pairs)
-#if DTL_ABLATE == 3
-        if (false) {
-#else
-        if (is_pilot || occupied) {
-#endif
+        if (!ablated(3) && (is_pilot || occupied)) {
             const cf32 eqv = cdiv(y, Hk);
             cf32 ref;
             if (is_pilot) {
@@ -1269,7 +1268,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
             for (int u = 0; u < nb; u++) buf[u * N + nat] = iq[(size_t(blockIdx.x) * L + (i0 + u)) * N + tid];
             __syncthreads();
         } else {
-            load_and_fft4<DTL_ABLATE>(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
+            load_and_fft4<kAblate>(t, iq, n_samples, fd.trigger, 2 + h + i0, nb, segs, n_segs, sw, buf, tw);
         }
         stage_begin();
         if constexpr (FUSED) {
@@ -1411,11 +1410,8 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     const cf32* pts = t.cnst_pts + cnst * 16;
     const float npwr = float(sqrt(stats[f].noise_lin)); // sigma = sqrt(noise) passed as npwr (:101,144)
     const float rinv = float(1.0 / double(npwr));        // the correctly rounded single reciprocal
-#if DTL_ABLATE == 34
-    const cf32 s = { 0.3f + 1e-3f * float(q & 63), -0.9f + 1e-3f * float(threadIdx.x & 31) };
-#else
-    const cf32 s = soft_syms[size_t(f) * t.frame_capacity + q];
-#endif
+    const cf32 s = ablated(34) ? cf32{ 0.3f + 1e-3f * float(q & 63), -0.9f + 1e-3f * float(threadIdx.x & 31) }
+                               : soft_syms[size_t(f) * t.frame_capacity + q];
     const uint32_t base = frames[f].llr_off;
     float* dst = llr_out + size_t(base) + size_t(q) * bps;
     float o[4];
@@ -1439,9 +1435,7 @@ __global__ __launch_bounds__(256) void demap_kernel(RxTables t, const FrameDesc*
     default:
         if (ord) soft_demap_symbol<4, MODE, true>(s, pts, npwr, rinv, o);
         else soft_demap_symbol<4, MODE>(s, pts, npwr, rinv, o);
-#if DTL_ABLATE == 33
-        if (o[0] + o[1] + o[2] + o[3] != 12345.678f) break;
-#endif
+        if (ablated(33) && o[0] + o[1] + o[2] + o[3] != 12345.678f) break;
         if ((base & 3u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
         break;
@@ -1856,25 +1850,23 @@ int launch_trigger_angle(const cf32* iq, int64_t n, int N, const int64_t* trig, 
     return DTL_OK;
 }
 
-static size_t header_search_bytes(const RxTables& t)
+// participating carriers per round of the integer-offset search: the largest power of two (<= 64) whose product table
+// (offsets x (chunk + 1) complex values) stays within 14 KB -- 1024-point headers: 16, 256-point: 64, 64-point: 32 (= all)
+static int header_search_chunk(const RxTables& t)
 {
     const int n_g = (t.g_max - t.g_min) / 2 + 1;
-    return size_t((n_g + 1) / 2) * (t.n_sync_act + 1) * sizeof(cf32); // two rounds over half of the offsets
-}
-
-// the products of the offset search live in LDS when they are few enough to leave room for several workgroups
-// per CU (and one lane per offset exists); otherwise each offset's lane forms its own products
-static bool header_search_in_lds(const RxTables& t)
-{
-    const int n_g = (t.g_max - t.g_min) / 2 + 1;
-    return n_g <= t.fft_len && t.n_sync_act > 0 && header_search_bytes(t) <= 28 * 1024;
+    int ch = 64;
+    while (ch > 1 && (size_t(n_g) * (ch + 1) * sizeof(cf32) > 14 * 1024 || ch / 2 >= std::max(t.n_sync_act, 1))) ch /= 2;
+    return ch;
 }
 
 size_t header_lds_bytes(const RxTables& t)
 {
+    const int n_g = (t.g_max - t.g_min) / 2 + 1;
     size_t b = size_t(2 + t.header_len + 1) * t.fft_len * sizeof(cf32) + size_t(t.fft_len) * sizeof(cf32) +
                size_t(t.fft_len / 2 + 2) * sizeof(float) + size_t((t.hdr_bits + 15) & ~15) +
-               size_t(t.fft_len) * sizeof(cf32) + (header_search_in_lds(t) ? header_search_bytes(t) : 0);
+               size_t(t.fft_len) * sizeof(cf32) + size_t(n_g) * (header_search_chunk(t) + 1) * sizeof(cf32) +
+               size_t(t.n_sync_act) * (sizeof(cf32) + sizeof(uint16_t)) + 16;
     return (b + 15) & ~size_t(15);
 }
 
@@ -1897,7 +1889,7 @@ int launch_header(const RxTables& t, const cf32* iq, int64_t n, const Candidate*
         attr_lds = lds;
     }
     hipLaunchKernelGGL(header_kernel<false>, dim3(n_cand), dim3(t.fft_len), lds, st, t, iq, n, cands,
-                       segs, n_segs, recs, taps, hdr_bits, header_search_in_lds(t) ? 1 : 0, HeaderStageIo{});
+                       segs, n_segs, recs, taps, hdr_bits, header_search_chunk(t), HeaderStageIo{});
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }
@@ -1913,7 +1905,7 @@ int launch_header_stage(const RxTables& t, int n, const HeaderStageIo& io, Heade
                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
     hipLaunchKernelGGL(header_kernel<true>, dim3(n), dim3(t.fft_len), lds, st, t, nullptr, int64_t(0), nullptr, nullptr, 0,
-                       recs, taps_out, hdr_bits, header_search_in_lds(t) ? 1 : 0, io);
+                       recs, taps_out, hdr_bits, header_search_chunk(t), io);
     DTL_HIP_CHECK(hipGetLastError());
     return DTL_OK;
 }
