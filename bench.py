@@ -240,20 +240,30 @@ def decoder_under_load(dtl, device, arith, ncw=1 << 20, esn0_db=-1.0, reps=3):
 LDPC_WAVE_INSTR_PER_ITERATION = {"gr_exact": 965, "fast": 665}
 
 
-def timed_steps(rx, x, steps, warmup, barrier):
+def timed_steps(rx, x, steps, warmup, barrier, pipelined=False):
     """W untimed + exactly K timed passes of the receive path; -> (elapsed s, last result, mean decoder-kernel ms,
-    mean payload-kernel ms, summed host stage ms)"""
+    mean payload-kernel ms, summed host stage ms).
+    pipelined: the K batches go through dtl_rx_submit / dtl_rx_wait -- batch k+1 is handed over before batch k is waited
+    for, so its sync kernels are queued behind batch k's last kernel and run while the host finishes batch k (records,
+    this loop).  Every batch is decoded completely inside the timed region; results are those of work()."""
     res = None
     ldpc_ms, payload_ms, stage = [], [], np.zeros(8)
     for _ in range(warmup):
         res = rx.work(x, copy_outputs=False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if pipelined:
+        rx.submit(x)
+    for i in range(steps):
         # results stay where the C ABI leaves them (payload bytes in HBM, per-frame / per-block records in the
         # handle's host memory); the numpy copies of the records are made on first read (after the timed region)
         res = None
-        res = rx.work(x, copy_outputs=False)
+        if pipelined:
+            if i + 1 < steps:
+                rx.submit(x)
+            res = rx.wait(copy_outputs=False)
+        else:
+            res = rx.work(x, copy_outputs=False)
         stage += np.array(res.stage_ms)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -316,7 +326,7 @@ def workload_record(dtl, name, device, steps, barrier, arith, seed):
     rx = dtl.ofdm_receiver(cfg)
     x, n_frames, n_user, _ = synth_stream(dtl, cfg, w, w["frames"], device, seed=seed)
     torch.cuda.synchronize()
-    elapsed, res, t_ldpc, t_payload, stage = timed_steps(rx, x, steps, 2, barrier)
+    elapsed, res, t_ldpc, t_payload, stage = timed_steps(rx, x, steps, 2, barrier, pipelined=True)
     st = decode_stats(rx, x, res, n_user)
     st["crc_ok_frac"] = round(st["tbs_crc_ok"] / max(1, st["tbs"]), 4)
     bps = w["bytes_per_sample"] or (8.0 + st["payload_bytes"] / x.numel())
@@ -515,6 +525,8 @@ def main():
     ap.add_argument("--esn0", type=float, default=None, help="override the workload's Es/N0 (dB)")
     ap.add_argument("--arith", default="gr_exact", choices=("gr_exact", "fast"),
                     help="arithmetic of the headline line (default: the reference's operations)")
+    ap.add_argument("--no-pipeline", action="store_true", help="time plain dtl_rx_process calls instead of the "
+                    "dtl_rx_submit / dtl_rx_wait pipeline (the next batch's sync kernels queued before the current batch's epilogue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fast arithmetic, other "
                     "operating points, decoder under load, root-fed exchange)")
@@ -644,7 +656,8 @@ def main():
 
     from gr_dtl_amd.sharding import combine
     cdev = None if rehearsal else device
-    elapsed, res, t_ldpc, t_payload, stage = timed_steps(rx, x, args.steps, args.warmup, barrier)
+    pipelined = not args.no_pipeline
+    elapsed, res, t_ldpc, t_payload, stage = timed_steps(rx, x, args.steps, args.warmup, barrier, pipelined=pipelined)
     # max-over-ranks time, summed counters (two tiny all-reduces; no data-path collective)
     elapsed, tot = combine(elapsed, [n_samples, res.n_payload_bytes, res.n_payload_frames, res.n_codewords], dist, cdev)
     total_samples = float(tot[0])
@@ -653,12 +666,17 @@ def main():
 
     extras = {}
     other = "fast" if args.arith == "gr_exact" else "gr_exact"
+    if pipelined and not args.no_extras:
+        e0, _, l0, p0, st0 = timed_steps(rx, x, args.steps, 1, barrier, pipelined=False)
+        e0, tot0 = combine(e0, [n_samples], dist, cdev)
+        extras["plain_calls"] = {"ms_per_step": round(e0 / args.steps * 1e3, 3), "value": round(float(tot0[0]) * args.steps / e0 / 1e6, 3),
+                                 "unit": "Msamples/s", "note": "the same steps as plain dtl_rx_process calls (no hand-over ahead)"}
     if not args.no_extras:
         # (1) the same step in the other arithmetic, on every rank (same input, same barriers, max over ranks)
         cfg2 = build_config(dtl, w)
         cfg2.arith = other
         rx2 = dtl.ofdm_receiver(cfg2)
-        e2, res2, l2, p2, _ = timed_steps(rx2, x, args.steps, 1, barrier)
+        e2, res2, l2, p2, _ = timed_steps(rx2, x, args.steps, 1, barrier, pipelined=pipelined)
         e2, tot2 = combine(e2, [n_samples], dist, cdev)
         extras["other_arith"] = {"arith": other, "ms_per_step": round(e2 / args.steps * 1e3, 3),
                                  "value": round(float(tot2[0]) * args.steps / e2 / 1e6, 3), "unit": "Msamples/s",
@@ -726,6 +744,9 @@ def main():
                                           "blocks CRC-ok (DESIGN.md 6).  NOT comparable with round 2's line, which ran the same "
                                           "batch at 18 dB (all frames found, no block decodable: the decoder's worst case): "
                                           "that point is measured in every run -> `comparable_18dB`",
+                       "step": ("one batch through dtl_rx_submit / dtl_rx_wait: batch k+1's sync kernels are queued behind batch k's "
+                                "last kernel, every batch is decoded completely inside the timed region (extra.plain_calls: the "
+                                "same steps as plain dtl_rx_process calls)") if pipelined else "one dtl_rx_process call per batch",
                        "parallelism": "frame-batch shard per GPU (dp%d), no data-path collective" % world},
             "roofline": roof,
             "stats": st,
@@ -734,7 +755,7 @@ def main():
     if args.workload in COMPARABLE_POINT and args.esn0 is None and world == 1:
         wc = dict(w, esn0_db=COMPARABLE_POINT[args.workload])
         xc, nfc, nuc, _ = synth_stream(dtl, cfg, wc, n_frames_req, device, seed=rank)
-        ec, resc, lc, pc, _ = timed_steps(rx, xc, 3, 1, barrier)
+        ec, resc, lc, pc, _ = timed_steps(rx, xc, 3, 1, barrier, pipelined=pipelined)
         if rank == 0:
             out["comparable_18dB"] = {"esn0_db": wc["esn0_db"], "arith": args.arith, "ms_per_step": round(ec / 3 * 1e3, 3),
                                       "value": round(xc.numel() * 3 / ec / 1e6, 3), "unit": "Msamples/s",
@@ -758,7 +779,7 @@ def main():
                     continue                                   # measured above in every run (comparable_18dB)
                 w3 = dict(w, esn0_db=esn0)
                 x3, nf3, nu3, _ = synth_stream(dtl, cfg, w3, n_frames_req, device, seed=rank)
-                e3, res3, l3, p3, _ = timed_steps(rx, x3, 3, 1, barrier)
+                e3, res3, l3, p3, _ = timed_steps(rx, x3, 3, 1, barrier, pipelined=pipelined)
                 rec = {"esn0_db": esn0, "arith": args.arith, "ms_per_step": round(e3 / 3 * 1e3, 3),
                        "value": round(x3.numel() * 3 / e3 / 1e6, 3), "ldpc_kernel_ms": round(l3, 3)}
                 rec.update(decode_stats(rx, x3, res3, nu3))

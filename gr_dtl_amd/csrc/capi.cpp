@@ -301,15 +301,9 @@ int dtl_tx_process(dtl_tx* h, const uint8_t* d_user, int64_t n_user, int32_t con
 
 void dtl_rx_destroy(dtl_rx* h) { delete h; }
 
-static int rx_run(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, int mode, void* stream, dtl_rx_result* out)
+static void fill_result(dtl_rx* h, uint32_t flags, dtl_rx_result* out)
 {
-    if (!h || !out) { dtl::set_last_error("rx_process: null argument"); return DTL_ERR_INVALID_ARG; }
-    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
     dtl::Receiver& r = h->rx;
-    const auto* iq = reinterpret_cast<const dtl::cf32*>(d_iq);
-    auto* st = static_cast<hipStream_t>(stream);
-    int rc = mode < 0 ? r.process(iq, n, flags, st) : r.process_stream(iq, n, flags, mode != 0, st);
-    if (rc != DTL_OK) return rc;
     std::memset(out, 0, sizeof(*out));
     out->n_frames = int64_t(r.frames.size());
     out->n_payload_frames = r.n_payload_frames;
@@ -337,7 +331,41 @@ static int rx_run(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, int m
     out->frame_capacity = r.frame_capacity();
     out->hdr_bits = r.hdr_bits();            // the row stride of d_hdr_bits (RxTables.hdr_bits)
     out->frame_samples = r.frame_samples();
+}
+
+static int rx_run(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, int mode, void* stream, dtl_rx_result* out)
+{
+    if (!h || !out) { dtl::set_last_error("rx_process: null argument"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    if (h->rx.queued()) { dtl::set_last_error("rx_process: batches of dtl_rx_submit are waiting (dtl_rx_wait first)"); return DTL_ERR_INVALID_ARG; }
+    dtl::Receiver& r = h->rx;
+    const auto* iq = reinterpret_cast<const dtl::cf32*>(d_iq);
+    auto* st = static_cast<hipStream_t>(stream);
+    int rc = mode < 0 ? r.process(iq, n, flags, st) : r.process_stream(iq, n, flags, mode != 0, st);
+    if (rc != DTL_OK) return rc;
+    fill_result(h, flags, out);
     return DTL_OK;
+}
+
+int dtl_rx_submit(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void* stream)
+{
+    DTL_API_BEGIN("dtl_rx_submit")
+    if (!h) { dtl::set_last_error("rx_submit: null handle"); return DTL_ERR_INVALID_ARG; }
+    if (dtl_device_count() <= 0) { dtl::set_last_error("no HIP device: the HIP path has no CPU fallback"); return DTL_ERR_NO_DEVICE; }
+    return h->rx.submit(reinterpret_cast<const dtl::cf32*>(d_iq), n, flags, static_cast<hipStream_t>(stream));
+    DTL_API_END
+}
+
+int dtl_rx_wait(dtl_rx* h, dtl_rx_result* out)
+{
+    DTL_API_BEGIN("dtl_rx_wait")
+    if (!h || !out) { dtl::set_last_error("rx_wait: null argument"); return DTL_ERR_INVALID_ARG; }
+    unsigned flags = 0;
+    int rc = h->rx.wait(&flags);
+    if (rc != DTL_OK) return rc;
+    fill_result(h, flags, out);
+    return DTL_OK;
+    DTL_API_END
 }
 
 int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void* stream, dtl_rx_result* out)

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
                                                                      int max_it, float sigma,
                                                                      uint8_t* __restrict__ out_bits,
                                                                      int32_t* __restrict__ out_nit,
-                                                                     unsigned int* __restrict__ queue, int chunk, int packed, int split_iterations)
+                                                                     unsigned int* __restrict__ queue, int chunk, int packed, int split_iterations, int steal)
 {
     static_assert(MAXC <= 4, "a variable's slot indices are read as one 64-bit word");
     extern __shared__ unsigned char np_smem[];
@@ -340,19 +340,22 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
         m.n_recv = min(m.n_sent, m.len0 + m.len1);     // beyond: sent but never received
     };
     // Soft bits of one codeword in on-air order, lane l holds positions l, l+64, ... (coalesced).  The loads are
-    // unconditional -- a lane outside the received part reads the codeword's last received soft bit (or the word at
-    // off0: always a valid soft bit of the stream) -- and their values are put right (`settle`) only where the
-    // codeword becomes the current one: no branch and no use of a loaded value near the loads, so the requests go out
-    // back to back and nothing waits for them here.
+    // unconditional -- a lane outside the received part reads the codeword's last received soft bit -- and their
+    // values are put right (`settle`) only where the codeword becomes the current one: no branch and no use of a loaded
+    // value near the loads, so the requests go out back to back and nothing waits for them here.  A codeword that
+    // received NOTHING (len0 == len1 == 0: it lies in a gap) reads soft bit 0 of the stream, whatever its offsets say:
+    // always a valid address of the caller's buffer (a descriptor with len0 == 0 and a stale llr_off1 used to be
+    // dereferenced at off1).
     auto fetch = [&](const Meta& m, float (&raw)[NV]) {
         const unsigned last = unsigned(max(m.n_recv, 1) - 1);
         // position i of the codeword is soft bit off0 + i of the stream, or off1 + (i - len0) behind a frame boundary:
         // one 32-bit sum either way (offsets are 32-bit stream positions; the wrap-around of `hop` cancels)
         const unsigned len0 = unsigned(m.len0), hop = m.off1 - m.off0 - len0;
+        const bool nothing = m.n_recv == 0;           // (wave-uniform)
 #pragma unroll
         for (int p = 0; p < NV; p++) {
             const unsigned i = min(unsigned(lane + p * kWave), last);
-            const uint32_t at = m.off0 + i + (i < len0 ? 0u : hop);
+            const uint32_t at = nothing ? 0u : m.off0 + i + (i < len0 ? 0u : hop);
             raw[p] = ablated(23) ? __uint_as_float(at | 0x80000000u) : llr[size_t(at)];
         }
     };
@@ -383,7 +386,12 @@ __global__ __launch_bounds__(kNpWaves * kWave) void ldpc_bp_np_kernel(LdpcTables
     // it is needed (it returns in order with the soft-bit loads the wave waits for anyway).
     const int n_chunks = n_big + n_tail;
     int chunk_next = 0, chunk_end = 0;
-    int home = int(blockIdx.x) % kNpQueues, queues_left = kNpQueues;
+    // steal == 0 (small batches): a wave draws from its workgroup's home counter only.  Every counter has its own waves (the
+    // workgroups with blockIdx % kNpQueues == q), which drain it completely, so nothing is left behind; what is given up is
+    // the balancing at the very end -- and what is saved are kNpQueues - 1 more same-address atomics per wave just to learn
+    // that the other counters have run out too (4096 waves x 7 probes, serialised per counter: ~50 us of a launch that
+    // otherwise takes 130 us for 4096 clean codewords)
+    int home = int(blockIdx.x) % kNpQueues, queues_left = steal ? kNpQueues : 1;
     unsigned pending = 0;                                 // lane 0: the reply to the outstanding request
     auto request = [&]() {
         unsigned v = 0;
@@ -887,8 +895,12 @@ int LdpcDecoder::decode(const float* d_llr, const CwDesc* d_desc, size_t ncw, ui
         // iterations whose variable pass forms the decisions first and divides only if the codeword goes on (see the kernel);
         // (DTL_LDPC_SPLIT_IT: tuning experiments)
         static const int split_it = [] { const char* e = std::getenv("DTL_LDPC_SPLIT_IT"); return e ? atoi(e) : kNpSplitIterations; }();
+        // taking tickets from the other counters when the home counter has run out pays once a wave has many codewords to
+        // balance (DTL_LDPC_STEAL_MIN: tuning experiments)
+        static const size_t steal_min = [] { const char* e = std::getenv("DTL_LDPC_STEAL_MIN"); return e ? size_t(atoll(e)) : size_t(1) << 17; }();
+        const int steal = (ncw >= steal_min || grid < kNpQueues) ? 1 : 0;   // (fewer workgroups than counters: some counter has no wave of its own)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kNpWaves * kWave), np_lds_, stream, t_, np_sh_, np_chk_var_, np_var_edge_, np_chk_deg_, np_chk_bits_,
-                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk, packed ? 1 : 0, split_it);
+                           d_llr, d_desc, int(ncw), max_iterations, sigma, d_bits, d_nit, queue, chunk, packed ? 1 : 0, split_it, steal);
         DTL_HIP_CHECK(hipGetLastError());
         return DTL_OK;
     }

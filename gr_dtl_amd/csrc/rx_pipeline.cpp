@@ -694,9 +694,11 @@ int Receiver::kernel_times(int back, double* ldpc_ms, double* payload_ms)
 
 Receiver::~Receiver()
 {
+    if (!queue_.empty()) (void)hipDeviceSynchronize();   // a queued batch's sync kernels may still be running on our buffers
     for (auto& slot : ev_ring_) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     for (auto& e : chunk_ev_) if (e) (void)hipEventDestroy(e);
     if (ev_stats_) (void)hipEventDestroy(ev_stats_);
+    if (ev_done_) (void)hipEventDestroy(ev_done_);
     for (auto& e : angle_ev_) if (e) (void)hipEventDestroy(e);
     for (auto& e : hdr_ev_) if (e) (void)hipEventDestroy(e);
     if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
@@ -1006,6 +1008,11 @@ struct Receiver::Call {
     bool spec_on = true;
     bool spec_carry_done = false; // the carried-over triggers have been offered to speculate_headers
     std::unique_ptr<FixSyncRun> fix; // frame_detect_bb over this call's trigger stream, fed range by range
+    // the sync kernel's sample ranges of this call (sync_launch): edges of range c at d_edges_ + off, its first `guess`
+    // entries copied to the pinned edge buffer together with the range's counter
+    struct Range { int64_t mb, me; unsigned max_edges, guess; size_t off; };
+    std::vector<Range> rg;
+    bool sync_launched = false;   // sync_launch has run for this call (possibly ahead of time: Receiver::submit)
     void lap(const char* what)
     {
         if (!dbg) return;
@@ -1013,6 +1020,15 @@ struct Receiver::Call {
         fprintf(stderr, "  [%s %.3f ms]\n", what, t - tdbg);
         tdbg = t;
     }
+};
+
+// a batch handed over by submit(); `call` exists once its sync kernels have been queued ahead of time
+struct Receiver::Queued {
+    const cf32* d_iq;
+    int64_t n;
+    unsigned flags;
+    hipStream_t st;
+    std::unique_ptr<Call> call;
 };
 
 // the stages were written as one function; they keep its local names through these aliases
@@ -1056,6 +1072,66 @@ int Receiver::stream_begin(Call& c)
     return DTL_OK;
 }
 
+// K1, device half: the sync kernel over the call's new samples in up to `sync_ranges_` sample ranges, each with its own
+// device -> host copy of the crossings and an event, all queued at once.  Needs nothing of the stream state beyond what
+// stream_begin has fixed (working buffer, A, B, E): for a self-contained batch it can run before the call itself starts
+// (Receiver::submit -- behind the previous batch's last kernel, so that the device goes on while the host finishes that
+// batch).
+int Receiver::sync_launch(Call& c)
+{
+    RX_CALL_LOCALS(c);
+    if (c.sync_launched) return DTL_OK;
+    c.sync_launched = true;
+    const int64_t mb0 = B - A;
+    // several ranges: what the host does for a range (sort, plateau detector, frame_detect_bb walk, oscillator phases,
+    // queueing the range's header kernel) runs while the device is busy with the next range's sync kernel and the
+    // header kernels queued so far
+    const int n_sc = n >= split_min_ ? sync_ranges_ : 1;
+    auto& rg = c.rg;
+    rg.clear();
+    size_t edge_slots = 0;
+    for (int k = 0; k < n_sc && n > 0; k++) {
+        int64_t mb = mb0 + n * k / n_sc, me = mb0 + n * (k + 1) / n_sc;
+        if (k) mb &= ~int64_t(kSyncTileSamples - 1);               // ranges meet on tile boundaries
+        if (k + 1 < n_sc) me &= ~int64_t(kSyncTileSamples - 1);
+        if (me <= mb) continue;
+        Call::Range r{ mb, me, unsigned(std::min<int64_t>(std::max<int64_t>((me - mb) / 8, 1024), 1 << 26)), 0, edge_slots };
+        // crossings expected in a stream of frames: two per preamble; copied back together with the counter
+        r.guess = unsigned(std::min<int64_t>(r.max_edges, 4 * ((me - mb) / frame_samples() + 1) + 1024));
+        edge_slots += r.max_edges;
+        rg.push_back(r);
+    }
+    if (rg.empty()) return DTL_OK;
+    DTL_TRY(d_edges_.ensure(edge_slots * 8));
+    DTL_TRY(d_counter_.ensure(64));
+    DTL_TRY(h_small_.ensure(128));   // range counters at 0 .. 63, the call's byte total at 96
+    size_t guess_total = 0;
+    for (auto& r : rg) guess_total += r.guess;
+    DTL_TRY(h_edges_.ensure(guess_total * 8));
+    DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 64, st));
+    float* metric = nullptr;
+    if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
+    while (chunk_ev_.size() < rg.size()) {
+        hipEvent_t e = nullptr;
+        DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        chunk_ev_.push_back(e);
+    }
+    size_t hoff = 0;
+    for (size_t k = 0; k < rg.size(); k++) {
+        const Call::Range& r = rg[k];
+        KC_BEGIN(st);
+        DTL_TRY(launch_sync_edges(iq, r.me, r.mb, N, cfg.sync_threshold, d_edges_.as<unsigned long long>() + r.off,
+                                  d_counter_.as<unsigned int>() + k, r.max_edges, metric ? metric + (r.mb - mb0) : nullptr, st));
+        KC_END(KernelClock::SYNC, st);
+        DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<unsigned>() + k, d_counter_.as<unsigned int>() + k, 4, hipMemcpyDeviceToHost, st));
+        DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.as<unsigned long long>() + hoff, d_edges_.as<unsigned long long>() + r.off,
+                                     size_t(r.guess) * 8, hipMemcpyDeviceToHost, st));
+        DTL_HIP_CHECK(hipEventRecord(chunk_ev_[k], st));
+        hoff += r.guess;
+    }
+    return DTL_OK;
+}
+
 // K1: Schmidl-Cox metric, threshold crossings, plateau detector
 int Receiver::stage_sync(Call& c)
 {
@@ -1069,53 +1145,10 @@ int Receiver::stage_sync(Call& c)
     double plateau_ms = 0.0;
     unsigned n_edges_total = 0;
     {
-        const int64_t mb0 = B - A;
-        // several ranges: what the host does for a range (sort, plateau detector, frame_detect_bb walk, oscillator phases,
-        // queueing the range's header kernel) runs while the device is busy with the next range's sync kernel and the
-        // header kernels queued so far
-        const int n_sc = n >= split_min_ ? sync_ranges_ : 1;
-        struct Range { int64_t mb, me; unsigned max_edges, guess; size_t off; };
-        std::vector<Range> rg;
-        size_t edge_slots = 0;
-        for (int c = 0; c < n_sc && n > 0; c++) {
-            int64_t mb = mb0 + n * c / n_sc, me = mb0 + n * (c + 1) / n_sc;
-            if (c) mb &= ~int64_t(kSyncTileSamples - 1);               // ranges meet on tile boundaries
-            if (c + 1 < n_sc) me &= ~int64_t(kSyncTileSamples - 1);
-            if (me <= mb) continue;
-            Range r{ mb, me, unsigned(std::min<int64_t>(std::max<int64_t>((me - mb) / 8, 1024), 1 << 26)), 0, edge_slots };
-            // crossings expected in a stream of frames: two per preamble; copied back together with the counter
-            r.guess = unsigned(std::min<int64_t>(r.max_edges, 4 * ((me - mb) / frame_samples() + 1) + 1024));
-            edge_slots += r.max_edges;
-            rg.push_back(r);
-        }
+        DTL_TRY(sync_launch(c));
+        using Range = Call::Range;
+        auto& rg = c.rg;
         if (!rg.empty()) {
-            DTL_TRY(d_edges_.ensure(edge_slots * 8));
-            DTL_TRY(d_counter_.ensure(64));
-            DTL_TRY(h_small_.ensure(128));   // range counters at 0 .. 63, the call's byte total at 96
-            size_t guess_total = 0;
-            for (auto& r : rg) guess_total += r.guess;
-            DTL_TRY(h_edges_.ensure(guess_total * 8));
-            DTL_HIP_CHECK(hipMemsetAsync(d_counter_.p, 0, 64, st));
-            float* metric = nullptr;
-            if (flags & RX_WANT_METRIC) { DTL_TRY(d_metric.ensure(size_t(n) * 4)); metric = d_metric.as<float>(); }
-            while (chunk_ev_.size() < rg.size()) {
-                hipEvent_t e = nullptr;
-                DTL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                chunk_ev_.push_back(e);
-            }
-            size_t hoff = 0;
-            for (size_t c = 0; c < rg.size(); c++) {
-                const Range& r = rg[c];
-                KC_BEGIN(st);
-                DTL_TRY(launch_sync_edges(iq, r.me, r.mb, N, cfg.sync_threshold, d_edges_.as<unsigned long long>() + r.off,
-                                          d_counter_.as<unsigned int>() + c, r.max_edges, metric ? metric + (r.mb - mb0) : nullptr, st));
-                KC_END(KernelClock::SYNC, st);
-                DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<unsigned>() + c, d_counter_.as<unsigned int>() + c, 4, hipMemcpyDeviceToHost, st));
-                DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.as<unsigned long long>() + hoff, d_edges_.as<unsigned long long>() + r.off,
-                                             size_t(r.guess) * 8, hipMemcpyDeviceToHost, st));
-                DTL_HIP_CHECK(hipEventRecord(chunk_ev_[c], st));
-                hoff += r.guess;
-            }
             lap("launch sync");
             // What the host does per range is two stages of a pipeline: (X) wait for the range's crossings, sort them,
             // run the plateau detector; (Y) frame_detect_bb walk, arg(P) at the triggers, oscillator phases, the range's
@@ -2023,7 +2056,18 @@ int Receiver::stage_blocks(Call& c)
             tbs[size_t(tix)] = ti;
         }
     }
-    DTL_HIP_CHECK(hipStreamSynchronize(st));
+    // everything of this batch is queued: the next batch of submit() starts behind it (its sync kernels run while the host
+    // waits here and builds this batch's records)
+    // (the host then waits for THIS batch's last operation -- an event --, not for the stream, which now also holds the next
+    // batch's kernels)
+    if (!queue_.empty() && !queue_.front()->call && queue_.front()->st == st) {
+        if (!ev_done_) DTL_HIP_CHECK(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
+        DTL_HIP_CHECK(hipEventRecord(ev_done_, st));
+        (void)prelaunch(*queue_.front());
+        DTL_HIP_CHECK(hipEventSynchronize(ev_done_));
+    } else {
+        DTL_HIP_CHECK(hipStreamSynchronize(st));
+    }
     if (kc_.on) DTL_TRY(kc_.collect());
     if (cfg.has_fec && n_tbs) std::memcpy(tb_res.data(), h_tbres_.p, size_t(n_tbs) * sizeof(TbResult));
     if (!cfg.has_fec && n_frames) std::memcpy(nofec_info.data(), h_nofec_.p, size_t(n_frames) * 8);
@@ -2145,7 +2189,53 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     return process_stream_body(d_iq, n, flags, final, st);
 }
 
-int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st)
+int Receiver::submit(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t st)
+{
+    if (n < 0 || (!d_iq && n > 0)) { set_last_error("submit: bad input"); return DTL_ERR_INVALID_ARG; }
+    if (n > int64_t(0x7fffffff)) { set_last_error("submit: at most 2^31-1 samples per batch"); return DTL_ERR_INVALID_ARG; }
+    if (queue_.size() >= 2) { set_last_error("submit: two batches are queued already (dtl_rx_wait takes the oldest)"); return DTL_ERR_CAPACITY; }
+    queue_.push_back(std::unique_ptr<Queued>(new Queued{ d_iq, n, flags, st, nullptr }));
+    // nothing is running between two calls on a handle: the only queued batch can start now (its sync kernels go out; a
+    // second one is started by the batch in front of it, behind that batch's last kernel -- stage_blocks)
+    if (queue_.size() == 1) (void)prelaunch(*queue_.front());
+    return DTL_OK;
+}
+
+// the sync kernels of a queued batch, ahead of its wait(): only what a fresh stream fixes without looking at the stream
+// state (no carried samples: A = B = 0).  Any failure leaves the batch to start normally inside wait().
+int Receiver::prelaunch(Queued& q)
+{
+    if (q.call || q.n <= 0 || (q.flags & (RX_WANT_METRIC | RX_WANT_KERNEL_SPLIT))) return DTL_OK;
+    if (cfg.has_fec && decoders_.size() < 2) return DTL_OK;             // (reported by the call itself)
+    DeviceScope dev;
+    if (dev.enter(cfg.device) != DTL_OK) return DTL_OK;
+    if (!uploaded_ && upload_tables() != DTL_OK) return DTL_OK;
+    auto c = std::make_unique<Call>();
+    c->d_iq = q.d_iq; c->iq = q.d_iq; c->n = q.n; c->W = q.n; c->flags = q.flags; c->final = true; c->st = q.st;
+    c->A = 0; c->B = 0; c->E = q.n;
+    c->N = cfg.fft_len; c->cp = cfg.cp_len; c->P = c->N + c->cp; c->h = cfg.header_len(); c->L = cfg.frame_length;
+    c->hdr_syms = 2 + c->h;
+    const bool was_on = kc_.on;
+    kc_.on = false;                                                     // (this launch belongs to no call's kernel clock)
+    const int rc = sync_launch(*c);
+    kc_.on = was_on;
+    if (rc == DTL_OK) q.call = std::move(c);
+    return DTL_OK;
+}
+
+int Receiver::wait(unsigned* flags_out)
+{
+    if (queue_.empty()) { set_last_error("wait: no batch is queued (dtl_rx_submit first)"); return DTL_ERR_INVALID_ARG; }
+    Queued q = std::move(*queue_.front());
+    queue_.erase(queue_.begin());
+    if (flags_out) *flags_out = q.flags;
+    DeviceScope dev;
+    DTL_TRY(dev.enter(cfg.device));
+    reset_stream();
+    return process_stream_body(q.d_iq, q.n, q.flags, true, q.st, std::move(q.call));
+}
+
+int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st, std::unique_ptr<Call> started)
 {
     StreamState& ss = *ss_;
     struct ResetOnExit { // a failed or final call ends the stream
@@ -2174,7 +2264,9 @@ int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, b
         ev_mask_[slot] = 0;
     }
     kc_.begin((flags & RX_WANT_KERNEL_SPLIT) != 0);
-    Call c;
+    // (a batch of submit() arrives with its sync kernels already queued: the same Call goes on)
+    std::unique_ptr<Call> own = started && started->n == n && started->d_iq == d_iq && !ss.carry_len ? std::move(started) : std::make_unique<Call>();
+    Call& c = *own;
     c.d_iq = d_iq; c.iq = d_iq; c.n = n; c.W = W; c.flags = flags; c.final = final; c.st = st;
     // A = absolute index of the working buffer's first sample (a multiple of the sync kernel's tile, so that
     // every metric value is computed exactly as in one batch); new samples are [B, E)

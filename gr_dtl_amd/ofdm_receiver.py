@@ -263,6 +263,8 @@ class ofdm_receiver:
         L.dtl_rx_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.POINTER(_Result)]
         L.dtl_rx_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int32, C.c_void_p,
                                             C.POINTER(_Result)]
+        L.dtl_rx_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p]
+        L.dtl_rx_wait.argtypes = [C.c_void_p, C.POINTER(_Result)]
         L.dtl_rx_reset.argtypes = [C.c_void_p]
         L.dtl_rx_reset.restype = None
         L.dtl_rx_stream_position.argtypes = [C.c_void_p]
@@ -421,14 +423,7 @@ class ofdm_receiver:
 
     def _run(self, iq, want, copy_outputs, final):
         import torch
-        if not (hasattr(iq, "is_cuda") and iq.is_cuda):
-            raise _lib.DtlError(_lib.ERR_NO_DEVICE, "ofdm_receiver.work needs a device tensor (no CPU fallback)")
-        if iq.dtype != torch.complex64:
-            raise ValueError("iq must be complex64")
-        iq = iq.contiguous().view(-1)
-        flags = 0
-        for w in want:
-            flags |= WANT.get(w, 0)
+        iq, flags = self._check_input(iq, want)
         res = _Result()
         st = _lib.current_stream_ptr()
         self._settle_last_result()
@@ -437,6 +432,39 @@ class ofdm_receiver:
         else:
             _lib.check(_lib.lib().dtl_rx_process_stream(self._h, iq.data_ptr(), iq.numel(), flags, int(final), st,
                                                         C.byref(res)))
+        return self._result(res, want, copy_outputs, iq.device, iq.numel(), st)
+
+    @staticmethod
+    def _check_input(iq, want):
+        import torch
+        if not (hasattr(iq, "is_cuda") and iq.is_cuda):
+            raise _lib.DtlError(_lib.ERR_NO_DEVICE, "ofdm_receiver.work needs a device tensor (no CPU fallback)")
+        if iq.dtype != torch.complex64:
+            raise ValueError("iq must be complex64")
+        flags = 0
+        for w in want:
+            flags |= WANT.get(w, 0)
+        return iq.contiguous().view(-1), flags
+
+    def submit(self, iq, want=()):
+        """work() in two halves (dtl_rx_submit / dtl_rx_wait): queue a self-contained batch -- at most two may wait.  While
+        the batch in front of it finishes, this one's sync kernels already run.  `iq` is kept alive until its wait()."""
+        iq, flags = self._check_input(iq, want)
+        if not hasattr(self, "_submitted"):
+            self._submitted = []
+        _lib.check(_lib.lib().dtl_rx_submit(self._h, iq.data_ptr(), iq.numel(), flags, _lib.current_stream_ptr()))
+        self._submitted.append((iq, tuple(want)))
+
+    def wait(self, copy_outputs=True):
+        """-> the rx_result of the oldest submitted batch (what work() returns for it)"""
+        res = _Result()
+        self._settle_last_result()
+        _lib.check(_lib.lib().dtl_rx_wait(self._h, C.byref(res)))
+        iq, want = getattr(self, "_submitted").pop(0)
+        return self._result(res, want, copy_outputs, iq.device, iq.numel(), _lib.current_stream_ptr())
+
+    def _result(self, res, want, copy_outputs, dev, n_in, st):
+        import torch
         out = rx_result()
         out.n_payload_frames = int(res.n_payload_frames)
         out.n_codewords = int(res.n_codewords)
@@ -450,7 +478,6 @@ class ofdm_receiver:
         out.n_payload_bytes = int(res.n_payload_bytes)
         if not copy_outputs:
             return out
-        dev = iq.device
 
         def grab(ptr, shape, dtype):
             t = torch.empty(shape, dtype=dtype, device=dev)
@@ -474,7 +501,7 @@ class ofdm_receiver:
             ncand = int(out.frames["cand"].max()) + 1 if nf else 0
             out.hdr_bits = grab(res.d_hdr_bits, (ncand, int(res.hdr_bits)), torch.uint8)
         if "metric" in want:
-            out.metric = grab(res.d_metric, (iq.numel(),), torch.float32)
+            out.metric = grab(res.d_metric, (n_in,), torch.float32)
         if "cw" in want and out.n_codewords:
             out.cw_nit = grab(res.d_cw_nit, (out.n_codewords,), torch.int32)
         return out

@@ -227,6 +227,19 @@ int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t fla
  * looks ahead only to the end of the buffer it is given (use_sync_correct = 0 removes that caveat). */
 int dtl_rx_process_stream(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t flags, int32_t final,
                           void* stream, dtl_rx_result* out);
+/* dtl_rx_process in two halves, for callers that decode batch after batch: dtl_rx_submit hands a self-contained batch
+ * over (at most two may be waiting), dtl_rx_wait runs the oldest one to its end and returns what dtl_rx_process would.
+ *     submit(b0); submit(b1); wait -> r0; submit(b2); wait -> r1; ...
+ * While batch k finishes -- its last kernels are queued, the host waits for them and builds the records -- the sync kernels
+ * of batch k + 1 are already behind them on the stream: the device does not idle between two batches (dtl_rx_process
+ * leaves it idle for the host's epilogue, the caller's own work and the next call's first launches).  d_iq must stay
+ * valid and unchanged from dtl_rx_submit to the dtl_rx_wait that returns the batch's result; results are bit-identical
+ * to dtl_rx_process on the same batch.  DTL_ERR_CAPACITY: two batches are queued already.  Not to be mixed with a
+ * running stream (dtl_rx_process_stream without final): every wait starts from a reset, like dtl_rx_process.
+ * Overlaps, in the reference's terms, the work() of ofdm_sync_sc_cfb on the next buffer with the FEC decoder's work() on
+ * the previous one (python/dtl/ofdm_receiver.py:71-98 vs :196-211) -- there, separate scheduler threads do that. */
+int dtl_rx_submit(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t flags, void* stream);
+int dtl_rx_wait(dtl_rx* h, dtl_rx_result* out);
 void dtl_rx_reset(dtl_rx* h);
 /* samples consumed since the last reset */
 int64_t dtl_rx_stream_position(const dtl_rx* h);

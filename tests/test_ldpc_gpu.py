@@ -186,3 +186,38 @@ def test_every_batch_size_is_decoded_once(oracle, dtl, cuda):
         else:                                             # ... and every smaller one against its prefix
             np.testing.assert_array_equal(nit, full_nit[:n], err_msg=f"batch of {n}")
             np.testing.assert_array_equal(bits, full_bits[:n], err_msg=f"batch of {n}")
+
+
+@pytest.mark.gpu
+def test_descriptor_that_received_nothing_reads_no_stale_offset(oracle, dtl, cuda):
+    """A codeword with len0 == len1 == 0 (it lies in a gap of the stream) whose offsets are stale -- far outside the caller's
+    buffer: the decoder must not dereference them (it reads soft bit 0 of the stream and drops it).  Decoded like the
+    oracle decodes "nothing received": every sent position 0, shortened positions -15."""
+    import torch
+    from gr_dtl_amd._lib import CwDesc
+    code = oracle.Ldpc(ALIST_300)
+    dec = dtl.ldpc_dec(ALIST_300)
+    rng = np.random.default_rng(12)
+    n, k = code.n, code.k
+    ncw = 70                                              # more than one wave's worth of tickets
+    descs, full = (CwDesc * ncw)(), np.zeros((ncw, n), np.float32)
+    buf = np.zeros(ncw * n + 16, np.float32)
+    pos = 0
+    for i in range(ncw):
+        cw = code.encode(rng.integers(0, 2, k).astype(np.uint8))
+        llr = ((2.0 * cw - 1) * 3 + rng.normal(0, 1, n)).astype(np.float32)
+        if i % 9 == 4:                                    # received nothing; offsets point 4 GB - 240 B into nowhere
+            descs[i] = CwDesc(0xFFFFFFF0, 0xFFFFFF00, i * k, 0, 0, k, 0)
+            full[i] = 0.0
+        else:
+            buf[pos:pos + n] = llr
+            descs[i] = CwDesc(pos, 0, i * k, n, 0, k, 0)
+            full[i] = llr
+            pos += n
+    ref_bits, ref_nit = code.decode_batch(full, n_threads=4)
+    d_desc = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(cuda)
+    bits = torch.zeros((ncw, k), dtype=torch.uint8, device=cuda)
+    nit = torch.zeros(ncw, dtype=torch.int32, device=cuda)
+    dec.decode_gather(torch.from_numpy(buf[:pos + 8]).to(cuda), d_desc, bits, nit)
+    np.testing.assert_array_equal(nit.cpu().numpy(), ref_nit)
+    np.testing.assert_array_equal(bits.cpu().numpy(), ref_bits)

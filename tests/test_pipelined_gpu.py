@@ -91,3 +91,78 @@ def test_pipelined_feed_with_carried_triggers(oracle, dtl, cuda, split_env):
     cuts = [n // 3 + 411, 2 * n // 3 + 1007]
     assert min(np.diff([0] + cuts + [n])) > 20000
     _assert_same(batch, _feed_all(rx, xt, cuts))
+
+
+def _same_result(a, b):
+    import torch
+    np.testing.assert_array_equal(a.raw_triggers, b.raw_triggers)
+    np.testing.assert_array_equal(a.fixed_triggers, b.fixed_triggers)
+    np.testing.assert_array_equal(a.sc_freq.view(np.uint32), b.sc_freq.view(np.uint32))
+    assert len(a.frames) == len(b.frames)
+    for k in FRAME_KEYS:
+        x, y = a.frames[k], b.frames[k]
+        np.testing.assert_array_equal(x.view(np.uint64) if x.dtype.kind == "f" else x, y.view(np.uint64) if y.dtype.kind == "f" else y, err_msg=k)
+    for k in TB_KEYS:
+        np.testing.assert_array_equal(a.tbs[k], b.tbs[k], err_msg=k)
+    assert torch.equal(a.payload, b.payload)
+    if a.llr is not None:
+        assert torch.equal(a.llr.view(torch.int32), b.llr.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [False, True])
+def test_submit_wait_equals_work_batch_by_batch(oracle, dtl, cuda, monkeypatch, split):
+    """dtl_rx_submit / dtl_rx_wait (the next batch's sync kernels are queued behind the running batch's last kernel): five
+    different batches through the two-deep queue return, one by one, exactly what work() returns for each -- triggers,
+    frame records, block records, soft bits and bytes -- with the single-range and the four-range sync stage."""
+    import torch
+    if split:
+        monkeypatch.setenv("DTL_RX_SPLIT_MIN", "20000")
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=64, sync_threshold=0.95)
+    batches = []
+    for i, (cnst, esn0, nb) in enumerate([(2, 13.0, 12000), (4, 24.0, 20000), (1, 20.0, 4000), (3, 21.0, 16000), (2, 14.0, 9000)]):
+        user, x = _jittered(oracle, ocfg, code, cnst, nb, esn0, seed=500 + i, drop_every=(6 if i % 2 else 0), jitter=i % 3)
+        batches.append(torch.from_numpy(x).to(cuda))
+    want = [dtl.ofdm_receiver(pcfg).work(x, want=("llr",)) for x in batches]
+    rx = dtl.ofdm_receiver(pcfg)
+    got = []
+    rx.submit(batches[0], want=("llr",))
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            rx.submit(batches[i + 1], want=("llr",))
+        got.append(rx.wait())
+    for a, b in zip(got, want):
+        _same_result(a, b)
+    assert sum(int((r.tbs["crc_ok"] == 1).sum()) for r in got) > 100
+    # the same handle goes on with plain calls
+    _same_result(rx.work(batches[1], want=("llr",)), want[1])
+
+
+@pytest.mark.gpu
+def test_submit_wait_queue_rules(oracle, dtl, cuda):
+    import torch
+    from gr_dtl_amd import _lib
+    pcfg, ocfg, code = make_pair(oracle, dtl)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 2, 3000, 13.0, seed=9)
+    xt = torch.from_numpy(x).to(cuda)
+    rx = dtl.ofdm_receiver(pcfg)
+    with pytest.raises(_lib.DtlError) as e:
+        rx.wait()
+    assert e.value.code == _lib.ERR_INVALID_ARG
+    rx.submit(xt)
+    rx.submit(xt)
+    with pytest.raises(_lib.DtlError) as e:
+        rx.submit(xt)                                  # two are waiting already
+    assert e.value.code == _lib.ERR_CAPACITY
+    with pytest.raises(_lib.DtlError):
+        rx.work(xt)                                    # a plain call while batches wait is refused
+    a, b = rx.wait(), rx.wait()
+    assert torch.equal(a.payload, b.payload) and a.payload.numel() > 0
+    ref = rx.work(xt)
+    assert torch.equal(ref.payload, a.payload)
+    # an empty batch and a handle destroyed with a batch waiting
+    rx.submit(xt[:0])
+    assert rx.wait().n_payload_bytes == 0
+    rx.submit(xt)
+    del rx
+    torch.cuda.synchronize()
