@@ -1276,20 +1276,29 @@ int Receiver::stage_sync(Call& c)
                     DTL_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
                     DTL_HIP_CHECK(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, greatest));
                 }
+                const size_t parts_before = c_.angle_parts.size();   // (a range without triggers submits nothing)
                 DTL_TRY(submit_angles(c_, first, trig.size(), side_));
                 lap("  range: submit angles");
                 if (!helper_on) { feed_fix(o); lap("  range: frame_detect"); }  // (no helper: everything on this thread)
-                // The oscillator segments of this range, then the headers of every trigger whose segments are complete
-                // and whose header symbols lie in front of `produced` (a later range decides what the others see):
-                // queued behind the sync kernels, they keep the device busy while the host deals with the next range
-                // -- and, for the last one, with frame_detect_bb's rest and the candidate list (stage_triggers).
+                // The oscillator segments, then the headers of every trigger whose segments are complete and whose header
+                // symbols lie in front of `produced` (a later range decides what the others see): queued behind the sync
+                // kernels, they keep the device busy while the host deals with the next range -- and, for the last one, with
+                // frame_detect_bb's rest and the candidate list (stage_triggers).  Skewed by one range: the angles of range
+                // c - 1 are taken when range c's arg(P) pass has been queued -- they have arrived by then, where waiting for
+                // them right behind their own submission cost a device round trip (0.27 ms) per range with the device idle.
                 // A call of a single range takes the unpipelined path (stage_frames launches everything).
-                if (!last || (c_.spec_on && !c_.hdr_launches.empty())) {
+                if (c > 0 && parts_before > 0) {
+                    DTL_TRY(collect_angles(c_, parts_before));   // ranges 0 .. c-1
+                    lap("  range: collect angles (previous range)");
+                    DTL_TRY(speculate_headers(c_, produced, false));
+                    lap("  range: speculate headers (previous range)");
+                }
+                if (last && c_.spec_on && !c_.hdr_launches.empty()) {
                     DTL_TRY(collect_angles(c_, c_.angle_parts.size()));
                     lap("  range: collect angles");
-                    DTL_TRY(speculate_headers(c_, last && final ? std::numeric_limits<int64_t>::max() : produced, last));
+                    DTL_TRY(speculate_headers(c_, final ? std::numeric_limits<int64_t>::max() : produced, true));
+                    lap("  range: speculate headers");
                 }
-                lap("  range: speculate headers");
             }
             if (helper_on) worker_->wait();
             if (fix_failed.load(std::memory_order_acquire)) { set_last_error("frame_detect walk: out of host memory"); return DTL_ERR_CAPACITY; }
