@@ -64,8 +64,9 @@ def test_c2_full_batch_matches_oracle(oracle, dtl, cuda):
 def test_c3_full_size_properties(oracle, dtl, cuda):
     import torch
     import bench
-    # the bench's C3 stream at an Es/N0 where most transport blocks pass their CRC (the bench line itself runs at the
-    # lowest Es/N0 that synchronises, where the round-trip property has nothing to check)
+    # the bench's C3 stream at the bench line's own operating point (23 dB: >= 99 % of the frames decoded and >= 90 % of
+    # the transport blocks CRC-ok) -- pinned here so that a change of the bench's point does not silently
+    # take the round-trip property's material away
     w = dict(bench.WORKLOADS["c3"], esn0_db=23.0)
     assert w["sync_threshold"] == 0.95
     cfg = bench.build_config(dtl, w)

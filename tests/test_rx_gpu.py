@@ -50,7 +50,10 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
     fix_ref = np.nonzero(ref["trig_fixed"])[0]
     np.testing.assert_array_equal(res.raw_triggers, raw_ref)
     np.testing.assert_array_equal(res.fixed_triggers, fix_ref)
-    _close(res.sc_freq, ref["angle"][raw_ref], rtol=1e-4, atol=2e-6, what="sc angle")
+    # arg(P) at the triggers: the kernel's atan2 and the oracle's are the same operations in the same order -- identical
+    # bits on all 734 streams of the rx / stream / fuzz suites (measured in round 4; the 1e-4 that stood here was a guess)
+    np.testing.assert_array_equal(np.asarray(res.sc_freq, np.float32).view(np.uint32),
+                                  np.asarray(ref["angle"][raw_ref], np.float32).view(np.uint32))
     # --- demux walk + header fields
     assert len(res.frames) == ref["n_frames"]
     N, L = ocfg.fft_len, ocfg.frame_length
