@@ -36,6 +36,15 @@ def _run_both(oracle, dtl, cuda, pcfg, ocfg, code, x, want_llr=True, max_frames=
 STATS = {"soft": [0, 0], "llr": [0, 0], "taps": [0, 0]}
 
 
+def _same_bits(got, want, what=""):
+    """Identical floats, bit for bit; a NaN matches any NaN (its payload bits are not defined by the operations)."""
+    got, want = np.ascontiguousarray(got), np.ascontiguousarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    g, w = got.view(np.float32).reshape(-1), want.view(np.float32).reshape(-1)
+    bad = (g.view(np.uint32) != w.view(np.uint32)) & ~(np.isnan(g) & np.isnan(w))
+    assert not bad.any(), (what, int(bad.sum()), g[bad][:4], w[bad][:4])
+
+
 def _count_exact(kind, got, want):
     got, want = np.ascontiguousarray(got), np.ascontiguousarray(want)
     same = (got.view(np.uint32) == want.view(np.uint32)) if got.dtype != np.complex64 else \
@@ -85,11 +94,13 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
             assert f[k] == rf["hdr"][k], (i, k)
         assert f["n_payload_syms"] == rf["n_payload_syms"]
         assert f["payload_index"] == pi
-        _close(taps[f["cand"]], ref["taps"][i], atol=1e-6 * N, what="taps")
+        _same_bits(taps[f["cand"]], ref["taps"][i], what="taps")      # 2.6 M taps of the rx + fuzz suites: identical bits
         _count_exact("taps", taps[f["cand"]], ref["taps"][i])
         # --- equaliser outputs
         h_ref, s_ref = ref["eq_hard"][i], ref["eq_soft"][i]
         np.testing.assert_array_equal(eq_hard[pi][used], h_ref[used])   # sliced symbols: exact
+        # identical bits but for the SIGN OF A ZERO real part: 12 of 17.4 M values in the rx + fuzz suites, all on carriers
+        # that hold nothing in their symbol -- the counter at the end of the module carries the claim
         _close(eq_soft[pi], s_ref, atol=2e-6, what="eq_soft frame %d" % i)
         _count_exact("soft", eq_soft[pi], s_ref)
         if not rf["snr_db"] >= 100.0:   # (NaN estimates compare as equal non-finite values)
@@ -107,7 +118,8 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
             if has_fec and noise_same:
                 nb = ns * rf["hdr"]["cnst"]
                 got = llr[f["llr_offset"]:f["llr_offset"] + nb]
-                _close(got, ref["llr"][i][:nb], rtol=1e-5, what="llr frame %d" % i)  # north_star: 1e-5 relative
+                # north_star asks for 1e-5 relative; the soft bits are the oracle's bits (23.6 M in the rx + fuzz suites)
+                _same_bits(got, ref["llr"][i][:nb], what="llr frame %d" % i)
                 _count_exact("llr", got, ref["llr"][i][:nb])
         pi += 1
     assert pi == res.n_payload_frames
