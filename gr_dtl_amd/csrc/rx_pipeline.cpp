@@ -108,6 +108,22 @@ int KernelClock::collect()
         longest[sp.kind] = std::max(longest[sp.kind], double(t));
         launches[sp.kind]++;
     }
+    if (getenv("DTL_KC_TIMELINE") && !spans.empty()) {
+        // (debugging aid) where the launches of the call sit on the device's clock, relative to the first one: the gaps
+        // the profiler's own overhead would otherwise distort
+        static const char* const names[N_KINDS] = { "sync_edges", "header", "frame_eq", "demap", "ldpc", "tb_check" };
+        double busy_until = 0.0, idle = 0.0;
+        for (const Span& sp : spans) {
+            float a = 0.0f, b = 0.0f;
+            DTL_HIP_CHECK(hipEventElapsedTime(&a, pool[spans[0].a], pool[sp.a]));
+            DTL_HIP_CHECK(hipEventElapsedTime(&b, pool[spans[0].a], pool[sp.b]));
+            const double gap = std::max(0.0, double(a) - busy_until);
+            idle += gap;
+            fprintf(stderr, "  kc %-10s start %8.3f dur %7.3f idle before %6.3f\n", names[sp.kind], double(a), double(b - a), gap);
+            busy_until = std::max(busy_until, double(b));
+        }
+        fprintf(stderr, "  kc span %.3f ms, not covered by a timed launch %.3f ms\n", busy_until, idle);
+    }
     valid = true;
     return DTL_OK;
 }
