@@ -28,6 +28,8 @@ struct HipError {
         hipError_t _e = (expr);                                                          \
         if (_e != hipSuccess) {                                                          \
             ::dtl::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));    \
+            (void)hipGetLastError(); /* reported: take it out of the runtime's "last error" slot, or the next     \
+                                        hipGetLastError() behind a launch -- of ANY handle -- reports it again */ \
             return DTL_ERR_HIP;                                                          \
         }                                                                                \
     } while (0)

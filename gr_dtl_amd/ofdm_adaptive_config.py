@@ -123,6 +123,8 @@ class ofdm_adaptive_rx_config(ofdm_adaptive_config):
     ldpc_max_iterations: int = 15
     arith: str = "gr_exact"     # "gr_exact": the reference's operations (its bits); "fast": production arithmetic
                                 # of the BP decoder and the 16-QAM demapper (include/dtl_rx.h, enum dtl_arith)
+    device: int = -1            # dtl_rx_cfg.device: the GPU this receiver's handle is bound to; -1 = whichever device is
+                                # current when a call is made (one process per GPU: the usual arrangement)
 
 
 @dc.dataclass

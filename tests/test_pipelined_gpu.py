@@ -166,3 +166,25 @@ def test_submit_wait_queue_rules(oracle, dtl, cuda):
     rx.submit(xt)
     del rx
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_handle_bound_to_a_device(oracle, dtl, cuda):
+    """dtl_rx_cfg.device: a handle created for device 0 behaves like one that takes the caller's current device, leaves
+    the caller's current device alone, and an index the machine does not have is a status at the first call."""
+    import dataclasses
+    import torch
+    from gr_dtl_amd import _lib
+    pcfg, ocfg, code = make_pair(oracle, dtl)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 2, 3000, 13.0, seed=21)
+    xt = torch.from_numpy(x).to(cuda)
+    want = dtl.ofdm_receiver(pcfg).work(xt)
+    bound = dtl.ofdm_receiver(dataclasses.replace(pcfg, device=0))
+    got = bound.work(xt)
+    assert torch.equal(got.payload, want.payload) and got.payload.numel() > 0
+    assert torch.cuda.current_device() == 0
+    far = dtl.ofdm_receiver(dataclasses.replace(pcfg, device=torch.cuda.device_count() + 3))
+    with pytest.raises(_lib.DtlError) as e:
+        far.work(xt)
+    assert e.value.code in (_lib.ERR_HIP, _lib.ERR_INVALID_ARG, _lib.ERR_NO_DEVICE), e.value
+    assert bound.work(xt).n_payload_bytes == want.n_payload_bytes          # the failed handle disturbed nobody
