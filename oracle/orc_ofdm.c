@@ -160,36 +160,42 @@ void orc_sync_sc(const orc_cfg* cfg, const orc_c32* iq, long n, float* metric_ou
      * of zeros is exactly zero (-> 0/0 = NaN, never above the threshold): a running sum would keep the
      * rounding residue of everything that went before, so the sums are cleared whenever their window
      * holds no non-zero term. */
+    /* A term that is not finite (a NaN / inf sample, products that overflow) spoils the FIR outputs whose window holds it
+     * and no others: such terms are kept out of the running sums and counted, and an output with one in either window has
+     * the metric NaN. */
     double pr = 0, pi = 0, en = 0;
-    long nz_c = 0, nz_e = 0;
+    long nz_c = 0, nz_e = 0, bad_c = 0, bad_e = 0;
+#define ORC_FIN(x) (fabsf(x) <= 3.4028234e38f)
     for (long i = 0; i < n; i++) {
-        cf cur = to_cf(iq[i]);
-        cf dly = (i >= half) ? to_cf(iq[i - half]) : 0;
-        cf c = cur * conjf(dly);
-        pr += crealf(c); pi += cimagf(c);
-        nz_c += (crealf(c) != 0.0f || cimagf(c) != 0.0f);
+        const orc_c32 cur = iq[i];
+        const orc_c32 zero = { 0, 0 };
+        const orc_c32 dly = (i >= half) ? iq[i - half] : zero;
+        const float cr = cur.re * dly.re + cur.im * dly.im, ci = cur.im * dly.re - cur.re * dly.im;   /* cur conj(dly) */
+        if (ORC_FIN(cr) && ORC_FIN(ci)) { pr += cr; pi += ci; nz_c += (cr != 0.0f || ci != 0.0f); }
+        else bad_c++;
         if (i >= half) {
-            cf co = to_cf(iq[i - half]);
-            cf dlo = (i - half >= half) ? to_cf(iq[i - 2 * half]) : 0;
-            cf cold = co * conjf(dlo);
-            pr -= crealf(cold); pi -= cimagf(cold);
-            nz_c -= (crealf(cold) != 0.0f || cimagf(cold) != 0.0f);
+            const orc_c32 co = iq[i - half];
+            const orc_c32 dlo = (i - half >= half) ? iq[i - 2 * half] : zero;
+            const float or_ = co.re * dlo.re + co.im * dlo.im, oi = co.im * dlo.re - co.re * dlo.im;
+            if (ORC_FIN(or_) && ORC_FIN(oi)) { pr -= or_; pi -= oi; nz_c -= (or_ != 0.0f || oi != 0.0f); }
+            else bad_c--;
         }
-        float e = crealf(cur) * crealf(cur) + cimagf(cur) * cimagf(cur);
-        en += 0.5f * e;
-        nz_e += (0.5f * e != 0.0f);
+        const float e = 0.5f * (cur.re * cur.re + cur.im * cur.im);
+        if (ORC_FIN(e)) { en += e; nz_e += (e != 0.0f); }
+        else bad_e++;
         if (i >= N) {
-            cf o = to_cf(iq[i - N]);
-            float eo = 0.5f * (crealf(o) * crealf(o) + cimagf(o) * cimagf(o));
-            en -= eo;
-            nz_e -= (eo != 0.0f);
+            const orc_c32 o = iq[i - N];
+            const float eo = 0.5f * (o.re * o.re + o.im * o.im);
+            if (ORC_FIN(eo)) { en -= eo; nz_e -= (eo != 0.0f); }
+            else bad_e--;
         }
         if (nz_c == 0) pr = pi = 0;
         if (nz_e == 0) en = 0;
         float Pr = (float)(-pr), Pi = (float)(-pi), E = (float)en;
         float num = Pr * Pr + Pi * Pi;
-        metric[i] = num / (E * E);
+        metric[i] = (bad_c || bad_e) ? NAN : num / (E * E);
     }
+#undef ORC_FIN
     /* plateau_detector_fb(max_len = cp_len, threshold), unbounded-buffer form */
     memset(trig, 0, n);
     for (long i = 0; i < n; i++) {
