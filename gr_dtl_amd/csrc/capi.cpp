@@ -178,6 +178,40 @@ static int fill_config(const dtl_rx_cfg* c, dtl::RxConfig& g, const char* who)
         dtl::set_last_error(std::string(who) + ": incomplete configuration");
         return DTL_ERR_INVALID_ARG;
     }
+    // The shape of the flattened arrays, before anything is read through them (what the values MEAN -- carrier indices,
+    // set sizes, code tables -- is checked by init() on the copies): every count bounds a pointer walk below.
+    auto refuse = [&](const char* what) {
+        dtl::set_last_error(std::string(who) + ": " + what);
+        return DTL_ERR_INVALID_ARG;
+    };
+    if (c->fft_len > 65536) return refuse("fft_len out of range");
+    if (c->cp_len < 0 || c->cp_len > c->fft_len) return refuse("bad cp_len");
+    if (c->frame_length < 1 || c->frame_length > 65535) return refuse("frame_length must lie in [1, 65535]");
+    if (c->n_occ_sets > 4096 || c->max_occ < 1 || c->max_occ > c->fft_len) return refuse("occupied carrier sets: bad shape");
+    for (int s = 0; s < c->n_occ_sets; s++)
+        if (c->occ_len[s] < 0 || c->occ_len[s] > c->max_occ) return refuse("occupied carrier set longer than max_occ (or negative)");
+    if (c->n_pilot_sets < 0 || c->n_pilot_sets > 4096 || c->n_pilots < 0 || c->n_pilots > c->fft_len) return refuse("pilot carrier sets: bad shape");
+    if (c->n_pilot_sets > 0 && c->n_pilots > 0 && !c->pilot_carriers) return refuse("pilot_carriers is null");
+    if (c->n_pilot_sym_sets < 0 || c->n_pilot_sym_sets > 65536) return refuse("pilot symbol sets: bad count");
+    if (c->n_pilot_sym_sets > 0 && c->n_pilots > 0 && !c->pilot_symbols) return refuse("pilot_symbols is null");
+    if (c->n_fec_codes < 0 || c->n_fec_codes > 255) return refuse("n_fec_codes must lie in [0, 255]");
+    if (c->n_fec_codes > 0 && (!c->alist_texts || !c->alist_lens)) return refuse("code tables: null array");
+    for (int i = 0; i < c->n_fec_codes; i++)
+        if (!c->alist_texts[i] || c->alist_lens[i] > (size_t(1) << 28)) return refuse("code table: null text or absurd length");
+    if (c->n_mcs < 0 || c->n_mcs > 4096) return refuse("n_mcs must lie in [0, 4096]");
+    if (c->n_mcs > 0 && (!c->mcs_snr || !c->mcs_cnst || !c->mcs_fec)) return refuse("MCS table: null array");
+    for (int i = 0; i < c->n_mcs; i++) {
+        if (c->mcs_cnst[i] < 1 || c->mcs_cnst[i] > 4) return refuse("MCS table: Unknown constellation");   // constellation_type_t
+        // (an index without a table is legal here: a handle may serve the single-block entry points only, and process()
+        // answers "Misconfiguration: decoder not found!" like the reference's decoder block)
+        if (c->mcs_fec[i] < 0 || c->mcs_fec[i] > 255) return refuse("MCS table: code index out of range");
+    }
+    if (c->n_mcs > 0 && (c->initial_mcs < 0 || c->initial_mcs >= c->n_mcs)) return refuse("initial_mcs outside the MCS table");
+    if (c->max_iterations < 0 || c->max_iterations > 100000) return refuse("max_iterations out of range");
+    if (!(c->sync_threshold == c->sync_threshold)) return refuse("sync_threshold is NaN");
+    if (!(c->eq_alpha >= 0.0f && c->eq_alpha <= 1.0f)) return refuse("eq_alpha must lie in [0, 1]");
+    if (!(c->bp_sigma >= 0.0f) || !(c->bp_sigma < 1.0e18f)) return refuse("bp_sigma must be a finite number >= 0");
+    if (!(c->hysteresis == c->hysteresis)) return refuse("hysteresis is NaN");
     g.fft_len = c->fft_len; g.cp_len = c->cp_len; g.frame_length = c->frame_length; g.has_fec = c->has_fec != 0;
     for (int s = 0; s < c->n_occ_sets; s++)
         g.occupied_carriers.emplace_back(c->occ + size_t(s) * c->max_occ, c->occ + size_t(s) * c->max_occ + c->occ_len[s]);
