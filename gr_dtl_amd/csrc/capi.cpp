@@ -557,7 +557,11 @@ int dtl_equalize_frames(dtl_rx* h, const float* d_frames, const float* d_taps, c
     for (int64_t i = 0; i < n; i++) {
         dtl::FrameDesc& d = descs[size_t(i)];
         d = dtl::FrameDesc{};
-        d.seg = -1; d.cand = int32_t(i); d.cnst = in_host[i].cnst; d.carr_offset = in_host[i].carr_offset;
+        d.seg = -1; d.cand = int32_t(i); d.cnst = in_host[i].cnst;
+        // at or beyond +-L N every shifted position falls outside the frame, and so does it for any larger offset: held to
+        // that range, the kernel's index sums stay inside the int range whatever the caller's tag says
+        const int32_t span = int32_t(std::min<int64_t>(int64_t(h->rx.cfg.frame_length) * h->rx.cfg.fft_len, 0x3fffffff));
+        d.carr_offset = std::min(std::max(in_host[i].carr_offset, -span), span);
         d.n_syms = std::max(0, std::min(in_host[i].n_payload_syms, h->rx.frame_capacity()));
     }
     return h->rx.equalize_frames(reinterpret_cast<const dtl::cf32*>(d_frames), reinterpret_cast<const dtl::cf32*>(d_taps),

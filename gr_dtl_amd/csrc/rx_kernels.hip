@@ -711,7 +711,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) void header_kernel(RxTable
     const int n_g = (t.g_max - t.g_min) / 2 + 1;
     const int n_act = t.n_sync_act;
     if (given_taps) {
-        if (tid == 0) s_off = io.carr_off_in[blockIdx.x];
+        // (a caller's offset: at or beyond +-h N every shifted position falls outside the header, and so does it for any
+        // larger value -- held to that range so that no later sum or negation of it can leave the int range)
+        if (tid == 0) s_off = min(max(io.carr_off_in[blockIdx.x], -h * N), h * N);
     } else if (ablated(41)) {
         if (tid < n_g) gabs[tid] = 0.0f;
     } else {

@@ -247,3 +247,44 @@ def test_equalizer_with_pilot_sets_of_different_sizes(oracle, dtl, cuda, cnst):
         np.testing.assert_array_equal(hard[f], h_ref.reshape(L, N))
         np.testing.assert_allclose(soft[f], s_ref.reshape(L, N), rtol=1e-5, atol=2e-6)
         assert abs(stats["snr_db"][f] - snr_db) <= 1e-6 * abs(snr_db) + 1e-6
+
+
+@pytest.mark.gpu
+def test_block_entry_points_with_absurd_carrier_offsets(oracle, dtl, cuda):
+    """The carrier offset handed to dtl_header_decode / dtl_equalize_frames is the caller's (a tag in the reference): at or
+    beyond +-(symbols x fft_len) every shifted position falls outside the block, so every larger value -- up to the ends of
+    the int range, where a sum or a negation would overflow -- must give what that one gives, and must not fault."""
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, frame_length=8)
+    user, hdrs, x = make_stream(oracle, ocfg, code, 2, 3000, 20.0, seed=77)
+    ref, frames = _frames_in_frequency_domain(oracle, ocfg, code, x)
+    rx = dtl.ofdm_receiver(pcfg)
+    h, L, N = ocfg.header_len, ocfg.frame_length, ocfg.fft_len
+    rows = torch.from_numpy(np.stack([r for _, _, r in frames[:6]])).to(cuda)
+    off, taps = rx.chanest(rows[:, 0:2])
+    imin, imax = -(1 << 31), (1 << 31) - 1
+    # ---- header: +-h N against the ends of the int range (and a value in between)
+    outs = {}
+    for v in (h * N, imax, 1 << 30, -h * N, imin, -(1 << 30)):
+        o = torch.full_like(off, v)
+        fields, taps_out, bits = rx.header_decode(rows[:, 2:2 + h], taps, o, want_bits=True)
+        outs[v] = (bits.cpu().numpy(), taps_out.cpu().numpy())
+        assert not fields["crc_ok"].any()
+    for big, edge in ((imax, h * N), (1 << 30, h * N), (imin, -h * N), (-(1 << 30), -h * N)):
+        np.testing.assert_array_equal(outs[big][0], outs[edge][0])
+    # ---- payload: the same at +-L N
+    fields, taps_out = rx.header_decode(rows[:, 2:2 + h], taps, off)
+    n = rows.shape[0]
+    res = {}
+    for v in (L * N, imax, -L * N, imin, 12345678):
+        hard, soft, syms, stats = rx.equalize_frames(rows[:, 2 + h:], taps_out, [2] * n, [v] * n, [ocfg.frame_capacity] * n)
+        res[v] = (hard.cpu().numpy(), syms.cpu().numpy())
+    for big, edge in ((imax, L * N), (12345678, L * N), (imin, -L * N)):
+        np.testing.assert_array_equal(_bits(res[big][0]), _bits(res[edge][0]))
+        np.testing.assert_array_equal(_bits(res[big][1]), _bits(res[edge][1]))
+    # and an ordinary call afterwards is the ordinary result
+    hard, soft, syms, stats = rx.equalize_frames(rows[:, 2 + h:], taps_out, [2] * n, [int(v) for v in off.cpu().numpy()], [ocfg.frame_capacity] * n)
+    for q in range(n):
+        i, f, r = frames[q]
+        if f["header_ok"]:
+            np.testing.assert_array_equal(hard.cpu().numpy()[q], ref["eq_hard"][i])
