@@ -21,7 +21,9 @@
 
 typedef float complex cf;
 
-static inline cf to_cf(orc_c32 v) { return v.re + v.im * I; }
+/* (CMPLXF, not re + im * I: without imaginary types that sum turns a real part of -0 into +0 whenever im >= 0, and an
+ * imaginary part of -0 into +0 always -- the reference's std::complex keeps both) */
+static inline cf to_cf(orc_c32 v) { return CMPLXF(v.re, v.im); }
 static inline orc_c32 from_cf(cf v) { return (orc_c32){ crealf(v), cimagf(v) }; }
 
 /* (a+ib)/(c+id) in float: Smith's algorithm written out, operation by operation -- what libgcc's __divsc3 computes
@@ -40,7 +42,7 @@ static inline cf cdiv(cf x, cf y)
         re = ((b * ratio) + a) / denom;
         im = (b - (a * ratio)) / denom;
     }
-    return re + im * I;
+    return CMPLXF(re, im);
 }
 
 /* carrier index (may be negative) -> position in a shifted FFT vector (DC at N/2) */
@@ -73,12 +75,12 @@ static void fft_inplace(cf* x, int n, int sign)
         for (int i = 0; i < n; i += len) {
             for (int k = 0; k < len / 2; k++) {
                 double ang = sign * 2.0 * M_PI * k / len;
-                cf w = (float)cos(ang) + (float)sin(ang) * I;
+                cf w = CMPLXF((float)cos(ang), (float)sin(ang));
                 cf u = x[i + k];
                 cf a = x[i + k + len / 2];
                 /* twiddle product with one fused multiply-add per component (the kernels do the same) */
-                cf v = __builtin_fmaf(crealf(a), crealf(w), -(cimagf(a) * cimagf(w))) +
-                       __builtin_fmaf(crealf(a), cimagf(w), cimagf(a) * crealf(w)) * I;
+                cf v = CMPLXF(__builtin_fmaf(crealf(a), crealf(w), -(cimagf(a) * cimagf(w))),
+                              __builtin_fmaf(crealf(a), cimagf(w), cimagf(a) * crealf(w)));
                 x[i + k] = u + v;
                 x[i + k + len / 2] = u - v;
             }
@@ -340,10 +342,10 @@ void orc_cfo_mix_trig(const orc_cfg* cfg, const orc_c32* iq, long n, const float
         }
         float ph = (float)phase, sn, cs;
         orc_sincosf(ph, &sn, &cs); /* sincosf with a fixed operation sequence, orc_math.h */
-        cf osc = cs + sn * I;
+        cf osc = CMPLXF(cs, sn);
         cf smp = (i >= dly) ? to_cf(iq[i - dly]) : 0;
-        cf r = (crealf(smp) * crealf(osc) - cimagf(smp) * cimagf(osc)) +
-               (crealf(smp) * cimagf(osc) + cimagf(smp) * crealf(osc)) * I;
+        cf r = CMPLXF(crealf(smp) * crealf(osc) - cimagf(smp) * cimagf(osc),
+                      crealf(smp) * cimagf(osc) + cimagf(smp) * crealf(osc));
         out[i] = from_cf(r);
     }
 }
@@ -414,7 +416,7 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
     for (int i = 0; i < n_sym; i++) {
         float ph = (float)(-(2.0 * M_PI) * carrier_offset * cp / N * (i + 1)), sn, cs;
         orc_sincosf(ph, &sn, &cs);
-        cf pc = cs + sn * I;
+        cf pc = CMPLXF(cs, sn);
         for (int k = 0; k < N; k++) out[(long)i * N + k] *= pc;
     }
     /* masks: ofdm_equalizer_1d_pilots ctor (input_is_shifted = true) + equalizer.cc:196-214 */
@@ -492,7 +494,7 @@ void orc_frame_equalize(const orc_cfg* cfg, int is_header, int cnst, const orc_c
     /* channel state out, rotated by the frame's accumulated phase (:189-193) */
     float ph = (float)((2.0 * M_PI) * carrier_offset * cp / N * n_sym), sn, cs;
     orc_sincosf(ph, &sn, &cs);
-    cf pc = cs + sn * I;
+    cf pc = CMPLXF(cs, sn);
     for (int k = 0; k < N; k++) taps_io[k] = from_cf(H[k] * pc);
     free(out); free(occupied); free(pilot_mask); free(pilot_sym); free(H);
 }

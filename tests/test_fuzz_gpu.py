@@ -447,4 +447,4 @@ def test_zz_fuzz_soft_values_are_the_oracles_bits():
     print("bit-identical fraction:", frac, {k: v[1] for k, v in STATS.items()})
     for kind, (same, total) in STATS.items():
         assert total > 100000, kind
-        assert same / total > 0.99999, (kind, same, total)
+        assert same == total, (kind, same, total)
