@@ -1313,9 +1313,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
 
     __syncthreads();                                  // s_pts, tw
     [[maybe_unused]] cf32 post_v = { 0.0f, 0.0f };    // FUSED: the symbol equalised from the zero row behind the frame (lag > 0)
+    // (the zero fill of the shift passes through the symbol's phase correction like every other position -- the
+    // reference clears the output, copies the shifted frame into it and then multiplies ALL of it -- which decides the
+    // signs of those zeros)
+    auto zero_at = [&](int i) -> cf32 {
+        cf32 pc = { 1.0f, -0.0f };
+        if (off != 0) pc = expj(float(-(2.0 * kPi) * off * t.cp_len / N * (i + 1)));
+        return cmul(cf32{ 0.0f, 0.0f }, pc);
+    };
     if (lag < 0) { // its source would be row -1: the zero fill of the shift
         stage_begin();
-        eq_step(0, cf32{ 0.0f, 0.0f });              // FUSED: destination 0 is always among the parked rows
+        eq_step(0, zero_at(0));                      // FUSED: destination 0 is always among the parked rows
         stage_end();
     }
     for (int i0 = 0; i0 < L; i0 += 4) {
@@ -1357,7 +1365,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(DEMAP >= 0 ? 4 : 5, DEMAP >= 0 ? 4
         stage_end();
         __syncthreads();                              // the next batch overwrites the scratch rows
     }
-    if (lag > 0) { stage_begin(); post_v = eq_step(L - 1, cf32{ 0.0f, 0.0f }); stage_end(); } // its source would be row L
+    if (lag > 0) { stage_begin(); post_v = eq_step(L - 1, zero_at(L - 1)); stage_end(); } // its source would be row L
 
     // combine the per-carrier Welford states (Chan); double, fixed tree order.  The reciprocals of the merged counts
     // (at most L x pilots-per-set of them) go to the FFT scratch first, which is free now.

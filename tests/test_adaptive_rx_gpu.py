@@ -57,7 +57,6 @@ def test_from_parameters_and_all_seven_ports(oracle, dtl, cuda, cnst, esn0):
     np.testing.assert_array_equal(ports[4].cpu().numpy(), want_hard)
     got_soft = ports[5].cpu().numpy()
     assert got_soft.shape == want_soft.shape
-    np.testing.assert_allclose(got_soft, want_soft, rtol=1e-5, atol=2e-6)
     assert (got_soft.view(np.uint32) == want_soft.view(np.uint32)).all()
     # 6: fine frequency offset, sampled at the raw triggers and held
     got_f, want_f = ports[6].cpu().numpy(), ref["angle"]

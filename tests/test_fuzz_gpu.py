@@ -373,9 +373,10 @@ def test_random_equalizer_inputs_match_oracle(oracle, dtl, cuda, seed):
 
     def same_or_close(a, b, what):
         a32, b32 = np.ascontiguousarray(a).view(np.float32), np.ascontiguousarray(b).view(np.float32)
-        ok = (a32 == b32) | (np.isnan(a32) & np.isnan(b32))
-        with np.errstate(all="ignore"):
-            ok |= np.abs(a32 - b32) <= 1e-5 * np.abs(b32) + 2e-6
+        # the oracle's bits; NaN matches NaN; a zero matches a zero of either sign (garbage in -- zero taps, NaN carriers --
+        # leaves zeros whose sign depends on how a 0 x NaN-free product was associated; on streams a transmitter produced
+        # the signs agree too: tests/test_rx_gpu.py compares those bit for bit)
+        ok = (a32.view(np.uint32) == b32.view(np.uint32)) | (np.isnan(a32) & np.isnan(b32)) | ((a32 == 0) & (b32 == 0))
         assert ok.all(), (what, int((~ok).sum()), a32[~ok][:4], b32[~ok][:4])
 
     with np.errstate(all="ignore"):

@@ -118,7 +118,6 @@ def check_against_oracle(oracle, pcfg, ocfg, code, rx, x, ports, tags, msgs, pro
     assert ports[4].shape == want_hard.shape
     np.testing.assert_array_equal(ports[4], want_hard)
     assert ports[5].shape == want_soft.shape
-    np.testing.assert_allclose(ports[5], want_soft, rtol=1e-5, atol=2e-6)
     assert (ports[5].view(np.uint32) == want_soft.view(np.uint32)).all()
     # ---- tags of the frame equaliser on both outputs, frame by frame
     keys = (HEADER_KEYS_FEC if has_fec else []) + HEADER_KEYS + ["noise_tag_key"] + \

@@ -105,10 +105,15 @@ def _compare(rx, res, ref, ocfg, has_fec, check_payload=True):
         _same_bits(eq_soft[pi], s_ref, what="eq_soft frame %d" % i)
         _count_exact("soft", eq_soft[pi], s_ref)
         if not rf["snr_db"] >= 100.0:   # (NaN estimates compare as equal non-finite values)
-            _close(f["snr_db"], rf["snr_db"], rtol=1e-6, atol=1e-6, what="snr")
-            _close(f["noise"], rf["noise_lin"], rtol=1e-5, what="noise")
-        else:   # a noise-free stream: the estimator measures float rounding -- one ulp in one of a few pilots moves it by dBs
+            # f64 Welford statistics: the kernel merges per-carrier states in a tree (Chan), the oracle runs through the pilots
+            # in the reference's order -- the last bits differ in 42 % of the frames.  Measured over the 13 569 noisy frames of
+            # the rx + fuzz suites: <= 1.5e-12 relative (noise), <= 6.5e-12 dB (SNR); the float the demapper takes from it
+            # (sqrt(noise) rounded once) is the same number, or the soft bits below would not be the oracle's bits
+            _close(f["snr_db"], rf["snr_db"], rtol=0.0, atol=1e-9, what="snr")
+            _close(f["noise"], rf["noise_lin"], rtol=1e-10, what="noise")
+        else:   # a noise-free stream: the estimator measures float rounding (measured: <= 3e-9 relative apart)
             assert f["snr_db"] > 100.0
+            _close(f["noise"], rf["noise_lin"], rtol=1e-6, what="noise of a noise-free frame")
         # (... and the soft bits scale with 1 / noise: compared only when the two estimates are the same number)
         noise_same = f["noise"] == rf["noise_lin"] or not rf["snr_db"] >= 100.0
         ill_conditioned |= not noise_same
