@@ -266,4 +266,24 @@ __device__ __forceinline__ void dm_sincos(float x, float* sn, float* cs)
     }
 }
 
+// sin and cos of a phase given in units of 2 pi / 2^32 (the fine-CFO oscillator, rx_types.h: CfoSegment): the quadrant is
+// the phase's top two bits (rounded), the rest a signed 30-bit number -> r in [-pi/4, pi/4) with one conversion and one
+// product -- no range test, no reduction; the kernels of dm_sincos on r.  (oracle: orc_sincos_phase, the same sequence)
+__device__ __forceinline__ void dm_sincos_phase(uint32_t a, float* sn, float* cs)
+{
+    const uint32_t q = (a + 0x20000000u) >> 30;
+    const float r = float(int32_t(a - (q << 30))) * float(3.14159265358979323846 / 2147483648.0);
+    const float z = r * r;
+    const float ps = __builtin_fmaf(z, __builtin_fmaf(z, __builtin_fmaf(z, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+    const float sp = __builtin_fmaf(r * z, ps, r);
+    const float pc = __builtin_fmaf(z, __builtin_fmaf(z, __builtin_fmaf(z, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+    const float cp = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    switch (q & 3u) {
+    case 0: *sn = sp; *cs = cp; break;
+    case 1: *sn = cp; *cs = -sp; break;
+    case 2: *sn = -sp; *cs = -cp; break;
+    default: *sn = -cp; *cs = sp; break;
+    }
+}
+
 } // namespace dtl

@@ -89,23 +89,49 @@ __device__ __forceinline__ SegWindow seg_window(const CfoSegment* __restrict__ s
     return w;
 }
 
-__device__ __forceinline__ float osc_phase(const CfoSegment* __restrict__ segs, int n_segs, const SegWindow& w,
-                                           int64_t i, float sens)
+__device__ __forceinline__ uint32_t osc_phase(const CfoSegment* __restrict__ segs, int n_segs, const SegWindow& w,
+                                              int64_t i, float /*sens*/)
 {
-    double ph = 0.0; // before the first trigger the held angle is 0
+    // phase0 + inc (i - start + 1) in units of 2 pi / 2^32, wrapping by itself (CfoSegment, rx_types.h); before the first
+    // trigger the held angle is 0 and the phase stays 0
+    uint32_t a = 0u;
     if (i >= w.c_start) {
         int seg = w.seg + 2;
         while (seg + 1 < n_segs && segs[seg + 1].start <= i) seg++;
         const CfoSegment s = segs[seg];
-        ph = s.phase0 + double(sens * s.angle) * double(i - s.start + 1);
+        a = s.phase0 + s.inc * uint32_t(i - s.start + 1);
     } else if (w.has_b && w.b.start <= i) {
-        ph = w.b.phase0 + double(sens * w.b.angle) * double(i - w.b.start + 1);
+        a = w.b.phase0 + w.b.inc * uint32_t(i - w.b.start + 1);
     } else if (w.has_a && w.a.start <= i) {
-        ph = w.a.phase0 + double(sens * w.a.angle) * double(i - w.a.start + 1);
+        a = w.a.phase0 + w.a.inc * uint32_t(i - w.a.start + 1);
     }
-    // wrap to [-pi, pi): ph - 2 pi floor((ph + pi) / 2 pi)
-    ph -= (2.0 * kPi) * floor((ph + kPi) * (1.0 / (2.0 * kPi)));
-    return float(ph);
+    return a;
+}
+// the phases of the four samples i, i + stride, i + 2 stride, i + 3 stride (a lane's samples of one OFDM symbol): when they
+// lie inside ONE of the window's two segments -- nearly always -- one product for the first and three additions of
+// inc x stride (the same numbers mod 2^32 as four evaluations); otherwise sample by sample
+__device__ __forceinline__ void osc_phase4(const CfoSegment* __restrict__ segs, int n_segs, const SegWindow& w, int64_t i,
+                                           int stride, float sens, uint32_t (&a)[4])
+{
+    const int64_t last = i + 3 * int64_t(stride);
+    const bool in_b = w.has_b && w.b.start <= i && last < w.c_start;
+    const bool in_a = w.has_a && w.a.start <= i && last < (w.has_b ? w.b.start : w.c_start);
+    if (in_a || in_b) {
+        const uint32_t p0 = in_b ? w.b.phase0 : w.a.phase0, inc = in_b ? w.b.inc : w.a.inc;
+        const int64_t st = in_b ? w.b.start : w.a.start;
+        const uint32_t step = inc * uint32_t(stride);
+        a[0] = p0 + inc * uint32_t(i - st + 1);
+        a[1] = a[0] + step; a[2] = a[1] + step; a[3] = a[2] + step;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = osc_phase(segs, n_segs, w, i + int64_t(j) * stride, sens);
+    }
+}
+__device__ __forceinline__ cf32 expj_phase(uint32_t a)
+{
+    float s, c;
+    dm_sincos_phase(a, &s, &c);
+    return { c, s };
 }
 
 // Load up to four consecutive OFDM symbols (sym0 .. sym0+n_sym-1) of the frame cut at `trigger` (delay N+cp,
@@ -159,11 +185,10 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
                 br[j] = t.bitrev[sidx];               // bit-reversed and swizzled
                 v[j] = cf32{ inside ? val.re : 0.0f, inside ? val.im : 0.0f };
             }
+            uint32_t ph[4] = { 0u, 0u, 0u, 0u };
+            if constexpr (!(ABL == 1 || ABL == 42)) osc_phase4(segs, n_segs, seg, i0 + q, N >> 2, sens, ph);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int sidx = q + j * (N >> 2);
-                x[br[j]] = (ABL == 1 || ABL == 42) ? v[j] : cmul(v[j], expj(osc_phase(segs, n_segs, seg, i0 + sidx, sens)));
-            }
+            for (int j = 0; j < 4; j++) x[br[j]] = (ABL == 1 || ABL == 42) ? v[j] : cmul(v[j], expj_phase(ph[j]));
         }
     } else {
         const int br = t.bitrev[tid];                 // bit-reversed and swizzled
@@ -175,13 +200,11 @@ __device__ __forceinline__ void load_and_fft4(const RxTables& t, const cf32* __r
             const cf32 val = iq[inside ? src : 0];
             v[uu] = cf32{ inside ? val.re : 0.0f, inside ? val.im : 0.0f };
         }
+        uint32_t ph[4] = { 0u, 0u, 0u, 0u };           // (a thread's four samples are one symbol period apart)
+        if constexpr (!(ABL == 1 || ABL == 42)) osc_phase4(segs, n_segs, seg, trigger + int64_t(sym0) * P + t.cp_len + tid, P, sens, ph);
 #pragma unroll
-        for (int uu = 0; uu < 4; uu++) {
-            if (uu < n_sym) {
-                const int64_t i = trigger + int64_t(sym0 + uu) * P + t.cp_len + tid;
-                buf[uu * N + br] = (ABL == 1 || ABL == 42) ? v[uu] : cmul(v[uu], expj(osc_phase(segs, n_segs, seg, i, sens)));
-            }
-        }
+        for (int uu = 0; uu < 4; uu++)
+            if (uu < n_sym) buf[uu * N + br] = (ABL == 1 || ABL == 42) ? v[uu] : cmul(v[uu], expj_phase(ph[uu]));
     }
     sync_stage();
     int st = 0;

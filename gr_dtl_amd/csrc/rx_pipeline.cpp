@@ -1394,20 +1394,11 @@ int Receiver::collect_angles(Call& c, size_t parts)
         std::memcpy(trigger_angles.data() + ap.first, h_angle_.as<float>() + ap.first, ap.count * 4);
         for (size_t j = ap.first; j < ap.first + ap.count; j++) {
             CfoSegment& sg = ss.segs[c.first_new_seg + j];
-            sg.angle = trigger_angles[j];
-            sg.phase0 = 0.0;
+            sg.inc = osc_phase_step(sens * trigger_angles[j]);
+            sg.phase0 = 0u;
             if (c.first_new_seg + j > 0) {
                 const CfoSegment& pv = ss.segs[c.first_new_seg + j - 1];
-                double phase = pv.phase0 + double(sens * pv.angle) * double(sg.start - pv.start);
-                // fmod(phase + pi, 2 pi): for the usual argument in [0, 4 pi) the remainder is the argument itself
-                // or one exact subtraction (Sterbenz), i.e. what fmod returns, without its division loop
-                const double x = phase + M_PI, two_pi = 2.0 * M_PI;
-                if (x >= 0.0 && x < two_pi) phase = x;
-                else if (x >= two_pi && x < 2.0 * two_pi) phase = x - two_pi;
-                else phase = std::fmod(x, two_pi);
-                if (phase < 0) phase += 2.0 * M_PI;
-                phase -= M_PI;
-                sg.phase0 = phase;
+                sg.phase0 = pv.phase0 + pv.inc * uint32_t(sg.start - pv.start);     // (mod 2^32: the wrap)
             }
         }
     }

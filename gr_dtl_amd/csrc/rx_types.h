@@ -49,13 +49,22 @@ struct RxTables {
 };
 
 // A stretch of the stream over which the fine-CFO oscillator runs at one held angle
-// (sample_and_hold_ff + frequency_modulator_fc, ofdm_receiver.py:75,89).
+// (sample_and_hold_ff + frequency_modulator_fc, ofdm_receiver.py:75,89).  The phase is kept in units of 2 pi / 2^32
+// and wraps by itself: phase(i) = phase0 + inc (i - start + 1) mod 2^32, phase0 of the next segment = phase0 + inc x
+// (next start - start) -- integer arithmetic, the same on the host, in the kernels and in the oracle (orc_cfo_mix_trig);
+// the reference integrates a float and reads a 10-bit sine table (1e-4 rad), so any exact definition is ours to choose.
 struct CfoSegment {
-    int64_t start;   // first sample index at which `angle` is held
-    double phase0;   // oscillator phase just before `start`
-    float angle;     // arg(P) sampled at the trigger
-    int32_t pad;
+    int64_t start;    // first sample index at which the angle is held
+    uint32_t phase0;  // oscillator phase just before `start`
+    uint32_t inc;     // phase step per sample: osc_phase_step(sensitivity x held angle)
 };
+// radians per sample -> phase step (round to nearest, ties to even; anything that is not a finite, small number: 0)
+inline uint32_t osc_phase_step(float radians)
+{
+    const double v = double(radians) * (4294967296.0 / (2.0 * 3.14159265358979323846));
+    if (!(v > -9.0e15 && v < 9.0e15)) return 0u;
+    return uint32_t(int64_t(__builtin_llrint(v)));
+}
 
 // One Schmidl-Cox trigger handed to the header kernel (phase A).
 struct Candidate {

@@ -166,4 +166,23 @@ static inline void orc_sincosf(float x, float* sn, float* cs)
     }
 }
 
+/* sin and cos of a phase in units of 2 pi / 2^32 (the fine-CFO oscillator, orc_cfo_mix_trig): quadrant = the top two bits
+ * (rounded), the rest a signed 30-bit number -> r in [-pi/4, pi/4); the kernels of orc_sincosf on r */
+static inline void orc_sincos_phase(uint32_t a, float* sn, float* cs)
+{
+    const uint32_t q = (a + 0x20000000u) >> 30;
+    const float r = (float)(int32_t)(a - (q << 30)) * (float)(3.14159265358979323846 / 2147483648.0);
+    float z = r * r;
+    float ps = ORC_FMA(z, ORC_FMA(z, ORC_FMA(z, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+    float sp = ORC_FMA(r * z, ps, r);
+    float pc = ORC_FMA(z, ORC_FMA(z, ORC_FMA(z, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+    float cp = ORC_FMA(z * z, pc, ORC_FMA(-0.5f, z, 1.0f));
+    switch (q & 3u) {
+    case 0: *sn = sp; *cs = cp; break;
+    case 1: *sn = cp; *cs = -sp; break;
+    case 2: *sn = -sp; *cs = -cp; break;
+    default: *sn = -cp; *cs = sp; break;
+    }
+}
+
 #endif

@@ -301,47 +301,44 @@ void orc_fix_sync(orc_framedetect* s, const uint8_t* in, uint8_t* out, int len)
     if (!trigger_found) s->remainder += len;
 }
 
-/* delay(N+cp) ; frequency_modulator_fc(-2.0/N) ; multiply_cc.  The oscillator phase is kept in double and wrapped
- * to [-pi, pi) (the reference keeps a float accumulator and a fixed-point sin/cos table: ~1e-4 of its own error).
- * The held angle is constant between triggers, so the integral is written in closed form per segment instead of
- * as n sequential additions:
- *     phase(i) = wrap(phase0 + (double)(sens * angle) * (i - start + 1)),   i in [start, next start)
- *     phase0 of the next segment = wrap(phase0 + (double)(sens * angle) * (next start - start))
- * -- one rounding per sample instead of an accumulated one, and the form a parallel implementation can evaluate
- * for any sample on its own (the HIP kernel does: identical bits).  trig (may be NULL): the raw trigger flags; a
- * segment starts at every trigger, also when the new angle equals the old one.  Without it a segment starts where
- * the held angle changes. */
-static double wrap_segment_phase(double phase)
+/* delay(N+cp) ; frequency_modulator_fc(-2.0/N) ; multiply_cc.  The reference keeps a float phase accumulator and reads a
+ * fixed-point sine table (~1e-4 rad of its own error, and a result that depends on how many samples it has integrated):
+ * nothing a parallel implementation can reproduce, so the oscillator is DEFINED here.  The held angle is constant between
+ * triggers, and the phase is kept in units of 2 pi / 2^32 so that it wraps by itself:
+ *     step    = round_to_nearest_even((double)(sens * angle) * 2^32 / 2 pi)           (osc_phase_step)
+ *     phase(i) = phase0 + step * (i - start + 1)   mod 2^32,                            i in [start, next start)
+ *     phase0 of the next segment = phase0 + step * (next start - start)   mod 2^32
+ *     osc(i)  = (cos, sin)(phase(i)) by orc_sincos_phase: quadrant from the top two bits, polynomial kernels on the rest
+ * -- integer arithmetic any sample can be evaluated with on its own (the HIP kernels do: identical bits), quantised to
+ * 1.5e-9 rad.  (Rounds 1-3 used a double phase wrapped with floor(): the same idea at four times the instructions.)
+ * trig (may be NULL): the raw trigger flags; a segment starts at every trigger, also when the new angle equals the old
+ * one.  Without it a segment starts where the held angle changes. */
+/* radians per sample -> phase step in units of 2 pi / 2^32 (round to nearest, ties to even; anything that is not a
+ * finite, small number: 0) -- gr_dtl_amd/csrc/rx_types.h:osc_phase_step */
+static uint32_t osc_phase_step(float radians)
 {
-    const double two_pi = 2.0 * M_PI, x = phase + M_PI;
-    if (x >= 0.0 && x < two_pi) phase = x;
-    else if (x >= two_pi && x < 2.0 * two_pi) phase = x - two_pi;
-    else phase = fmod(x, two_pi);
-    if (phase < 0) phase += 2.0 * M_PI;
-    return phase - M_PI;
+    const double v = (double)radians * (4294967296.0 / (2.0 * M_PI));
+    if (!(v > -9.0e15 && v < 9.0e15)) return 0u;
+    return (uint32_t)(int64_t)llrint(v);
 }
 
 void orc_cfo_mix_trig(const orc_cfg* cfg, const orc_c32* iq, long n, const float* angle, const uint8_t* trig, orc_c32* out)
 {
     const int dly = cfg->fft_len + cfg->cp_len;
     const float sens = (float)(-2.0 / cfg->fft_len);
-    double phase0 = 0;
+    uint32_t phase0 = 0, inc = 0;
     long start = -1;       /* no segment yet: the held angle is 0 and the phase stays 0 */
-    float seg_angle = 0;
     for (long i = 0; i < n; i++) {
         const int new_seg = trig ? trig[i] : (i == 0 ? angle[0] != 0.0f : angle[i] != angle[i - 1]);
         if (new_seg) {
-            phase0 = (start >= 0) ? wrap_segment_phase(phase0 + (double)(sens * seg_angle) * (double)(i - start)) : 0.0;
+            phase0 = (start >= 0) ? phase0 + inc * (uint32_t)(i - start) : 0u;     /* mod 2^32: the wrap */
             start = i;
-            seg_angle = angle[i];
+            inc = osc_phase_step(sens * angle[i]);
         }
-        double phase = 0;
-        if (start >= 0) {
-            phase = phase0 + (double)(sens * seg_angle) * (double)(i - start + 1);
-            phase -= (2.0 * M_PI) * floor((phase + M_PI) * (1.0 / (2.0 * M_PI)));
-        }
-        float ph = (float)phase, sn, cs;
-        orc_sincosf(ph, &sn, &cs); /* sincosf with a fixed operation sequence, orc_math.h */
+        uint32_t a = 0;
+        if (start >= 0) a = phase0 + inc * (uint32_t)(i - start + 1);
+        float sn, cs;
+        orc_sincos_phase(a, &sn, &cs);          /* fixed operation sequence, orc_math.h */
         cf osc = CMPLXF(cs, sn);
         cf smp = (i >= dly) ? to_cf(iq[i - dly]) : 0;
         cf r = CMPLXF(crealf(smp) * crealf(osc) - cimagf(smp) * cimagf(osc),
