@@ -71,6 +71,10 @@ void orc_calc_soft_dec(int cnst, orc_c32 sample, float npwr, int dist_mode, floa
  * n_syms symbols -> n_syms*bps LLRs, LSB first per symbol.  noise<0 => no noise tag. */
 void orc_soft_demap(int cnst, const orc_c32* syms, int n_syms, double noise, int dist_mode,
                     float* llr_out);
+/* test hooks: the fixed-sequence math of orc_math.h over arrays */
+void orc_math_logf(const float* x, long n, float* y);
+void orc_math_expf(const float* x, long n, float* y);
+void orc_math_sincos_phase(const uint32_t* a, long n, float* sn, float* cs);
 
 /* ------------------------------------------------------------------ LDPC */
 

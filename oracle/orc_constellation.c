@@ -156,3 +156,8 @@ void orc_soft_demap(int cnst, const orc_c32* syms, int n_syms, double noise, int
         for (int j = 0; j < bps; j++) llr_out[i * bps + j] = msb[bps - 1 - j];
     }
 }
+
+/* test hooks: the fixed-sequence math of orc_math.h over arrays (tests/test_math_accuracy_cpu.py) */
+void orc_math_logf(const float* x, long n, float* y) { for (long i = 0; i < n; i++) y[i] = orc_logf(x[i]); }
+void orc_math_expf(const float* x, long n, float* y) { for (long i = 0; i < n; i++) y[i] = orc_expf(x[i]); }
+void orc_math_sincos_phase(const uint32_t* a, long n, float* sn, float* cs) { for (long i = 0; i < n; i++) orc_sincos_phase(a[i], &sn[i], &cs[i]); }
