@@ -528,11 +528,17 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="time plain dtl_rx_process calls instead of the "
                     "dtl_rx_submit / dtl_rx_wait pipeline (the next batch's sync kernels queued before the current batch's epilogue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="profiler runs: only the headline workload's steps touch the device -- "
+                    "no extras, no CPU baseline and not the 18 dB comparison either, so that rocprofv3's per-kernel averages are those of "
+                    "the bench line's own kernels (tools/profile_c3.sh, tools/pmc_sq.sh)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fast arithmetic, other "
                     "operating points, decoder under load, root-fed exchange)")
     ap.add_argument("--cpu-frames", type=int, default=0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (default: all, at most 16)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_extras = True
+        args.no_cpu_baseline = True
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent never touches
@@ -752,7 +758,7 @@ def main():
             "stats": st,
         }
     # the round-over-round figure: the same batch at round 2's operating point, in EVERY run (one rank's own shard)
-    if args.workload in COMPARABLE_POINT and args.esn0 is None and world == 1:
+    if args.workload in COMPARABLE_POINT and args.esn0 is None and world == 1 and not args.headline_only:
         wc = dict(w, esn0_db=COMPARABLE_POINT[args.workload])
         xc, nfc, nuc, _ = synth_stream(dtl, cfg, wc, n_frames_req, device, seed=rank)
         ec, resc, lc, pc, _ = timed_steps(rx, xc, 3, 1, barrier, pipelined=pipelined)

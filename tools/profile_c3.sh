@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): rocprofv3 kernel statistics + HBM traffic counters of the default bench.
-# (the profiled command is `bench.py --no-extras --no-cpu-baseline`: the headline step only, so that the per-kernel
+# (the profiled command is `bench.py --headline-only`: the headline step only, so that the per-kernel
 # averages are those of the bench line's kernels and not mixed with the secondary measurements of `extra`)
 # Three separate passes (kernel trace; FETCH_SIZE; WRITE_SIZE) as MI355X_MICROARCH.md prescribes.
 # Results land in gpurun_out/prof_<tag>/ ; tools/pmc_traffic.py condenses them into profiles/.
@@ -10,11 +10,11 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 OUT="$R/gpurun_out/prof_${TAG}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o c3 -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-extras --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o c3 -- python3 "$R/bench.py" --steps 5 --warmup 2 --headline-only > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "kernel-trace pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o c3 -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-extras --no-cpu-baseline > "$OUT/fetch.json" 2> "$OUT/fetch.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o c3 -- python3 "$R/bench.py" --steps 2 --warmup 1 --headline-only > "$OUT/fetch.json" 2> "$OUT/fetch.err"
 echo "FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o c3 -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-extras --no-cpu-baseline > "$OUT/write.json" 2> "$OUT/write.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o c3 -- python3 "$R/bench.py" --steps 2 --warmup 1 --headline-only > "$OUT/write.json" 2> "$OUT/write.err"
 echo "WRITE_SIZE pass done"
 python3 "$R/bench.py" --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 "$R/tools/pmc_traffic.py" "$OUT" "$TAG" c3

@@ -7,9 +7,9 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 OUT="$R/gpurun_out/prof_${TAG}"
 mkdir -p "$OUT/summary"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$W" -o "$W" -- python3 "$R/bench.py" --workload "$W" --steps 10 --warmup 3 --no-extras --no-cpu-baseline > "$OUT/summary/${W}_bench_under_rocprof.json" 2> "$OUT/stats_$W.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$W" -o "$W" -- python3 "$R/bench.py" --workload "$W" --steps 10 --warmup 3 --headline-only > "$OUT/summary/${W}_bench_under_rocprof.json" 2> "$OUT/stats_$W.err"
 KS="$(find "$OUT/stats_$W" -name '*kernel_stats.csv' | head -1)"
 cp "$KS" "$OUT/summary/${W}_kernel_stats.csv"
-python3 "$R/bench.py" --workload "$W" --steps 20 --warmup 3 --no-extras --no-cpu-baseline > "$OUT/summary/${W}_bench.json" 2> "$OUT/${W}_bench.err"
+python3 "$R/bench.py" --workload "$W" --steps 20 --warmup 3 --headline-only > "$OUT/summary/${W}_bench.json" 2> "$OUT/${W}_bench.err"
 find "$OUT/stats_$W" -name "*.csv" -size +20M -delete
 head -8 "$OUT/summary/${W}_kernel_stats.csv"
