@@ -718,6 +718,7 @@ Receiver::~Receiver()
     for (auto& e : angle_ev_) if (e) (void)hipEventDestroy(e);
     for (auto& e : hdr_ev_) if (e) (void)hipEventDestroy(e);
     if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
+    if (ev_pre_) (void)hipEventDestroy(ev_pre_);
 }
 
 int Receiver::init()
@@ -1139,10 +1140,14 @@ int Receiver::sync_launch(Call& c)
         DTL_TRY(launch_sync_edges(iq, r.me, r.mb, N, cfg.sync_threshold, d_edges_.as<unsigned long long>() + r.off,
                                   d_counter_.as<unsigned int>() + k, r.max_edges, metric ? metric + (r.mb - mb0) : nullptr, st));
         KC_END(KernelClock::SYNC, st);
-        DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<unsigned>() + k, d_counter_.as<unsigned int>() + k, 4, hipMemcpyDeviceToHost, st));
+        // (the range's counter and crossings on a stream of their own -- so that two sync kernels follow each other without the
+        // two copy dispatches in between -- measured: nothing for plain calls, +1.5 ms per step for batches handed over ahead,
+        // whose next sync kernels are already queued when these copies are issued; they stay on the main stream)
+        hipStream_t cp = st;
+        DTL_HIP_CHECK(hipMemcpyAsync(h_small_.as<unsigned>() + k, d_counter_.as<unsigned int>() + k, 4, hipMemcpyDeviceToHost, cp));
         DTL_HIP_CHECK(hipMemcpyAsync(h_edges_.as<unsigned long long>() + hoff, d_edges_.as<unsigned long long>() + r.off,
-                                     size_t(r.guess) * 8, hipMemcpyDeviceToHost, st));
-        DTL_HIP_CHECK(hipEventRecord(chunk_ev_[k], st));
+                                     size_t(r.guess) * 8, hipMemcpyDeviceToHost, cp));
+        DTL_HIP_CHECK(hipEventRecord(chunk_ev_[k], cp));
         hoff += r.guess;
     }
     return DTL_OK;
@@ -2000,18 +2005,32 @@ int Receiver::stage_blocks(Call& c)
             DTL_TRY(d_len_.ensure(size_t(n_tbs) * 4));
             DTL_TRY(d_offs_.ensure(size_t(n_tbs) * 4));
             DTL_TRY(d_staging_.ensure(size_t(n_tbs) * stride));
-            DTL_TRY(upload_vec(h_gather_, d_tbgather_, gathers, st));
-            if (!llr_copies.empty()) {
-                DTL_TRY(upload_vec(h_llrcopy_, d_llrcopy_, llr_copies, st));
-                DTL_TRY(launch_llr_gather(d_llrcopy_.as<LlrCopy>(), int(llr_copies.size()), d_llr.as<float>(), st));
-            }
-            DTL_TRY(launch_expand_cw(d_tbgather_.as<TbGather>(), n_tbs, d_cwdesc_.as<CwDesc>(), st));
-            if (ev_) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
+            // What the decoder needs besides the soft bits -- the blocks' gather recipes on the device, their expansion into
+            // codeword descriptors, the zeroed output words -- depends on the host's bookkeeping only, which is done while
+            // phase B is still running: it goes onto the side stream and executes UNDER the demapper's last launches (on the
+            // main stream these two copies, one small kernel and one fill sat between phase B and the decoder with the device
+            // waiting: 0.18 ms per step).  The decoder waits for the side stream's event.
             // the decoder packs its decisions (1 bit per bit) when every code in use runs on the node-parallel kernel:
             // an eighth of the bytes out and back in; the buffer is zeroed first (the kernel ORs words in)
             bool packed = true;
             for (auto& cr : code_ranges) packed = packed && decoders_[cr.first]->packed_output_ok();
-            if (packed) DTL_HIP_CHECK(hipMemsetAsync(d_cw_bits.p, 0, (size_t(bits_total) / 8 + 64 + 7) & ~size_t(7), st));
+            hipStream_t pre = st;
+            if (side_ && st != side_) {
+                pre = side_;
+                if (!ev_pre_) DTL_HIP_CHECK(hipEventCreateWithFlags(&ev_pre_, hipEventDisableTiming));
+            }
+            DTL_TRY(upload_vec(h_gather_, d_tbgather_, gathers, pre));
+            DTL_TRY(launch_expand_cw(d_tbgather_.as<TbGather>(), n_tbs, d_cwdesc_.as<CwDesc>(), pre));
+            if (packed) DTL_HIP_CHECK(hipMemsetAsync(d_cw_bits.p, 0, (size_t(bits_total) / 8 + 64 + 7) & ~size_t(7), pre));
+            if (pre != st) {
+                DTL_HIP_CHECK(hipEventRecord(ev_pre_, pre));
+                DTL_HIP_CHECK(hipStreamWaitEvent(st, ev_pre_, 0));
+            }
+            if (!llr_copies.empty()) {                // (rare: soft bits moved into one run -- they come from phase B: main stream)
+                DTL_TRY(upload_vec(h_llrcopy_, d_llrcopy_, llr_copies, st));
+                DTL_TRY(launch_llr_gather(d_llrcopy_.as<LlrCopy>(), int(llr_copies.size()), d_llr.as<float>(), st));
+            }
+            if (ev_) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
             for (auto& cr : code_ranges) {
                 KC_BEGIN(st);
                 DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,

@@ -268,6 +268,7 @@ private:
     std::vector<hipEvent_t> chunk_ev_; // one per candidate chunk of the phase A/B pipeline
     hipEvent_t ev_stats_ = nullptr;    // the per-frame SNR estimates have reached the host
     hipEvent_t ev_done_ = nullptr;     // a batch's last operation (the next batch of submit() is queued behind it)
+    hipEvent_t ev_pre_ = nullptr;      // the decoder's preparations on the side stream (stage_blocks)
     hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
     std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers
     std::vector<hipEvent_t> hdr_ev_;   // one per header-kernel launch of a call
