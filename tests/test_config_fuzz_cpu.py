@@ -25,6 +25,7 @@ first, last = int(sys.argv[1]), int(sys.argv[2])
 INTS = ["fft_len", "cp_len", "frame_length", "has_fec", "n_occ_sets", "max_occ", "n_pilot_sets", "n_pilots",
         "n_pilot_sym_sets", "use_sync_correct", "scramble_header", "llr_dist_mode", "max_iterations", "n_fec_codes",
         "n_mcs", "initial_mcs", "decision_th", "arith", "device"]
+COUNTS = {"n_occ_sets", "max_occ", "n_pilot_sets", "n_pilots", "n_pilot_sym_sets", "n_fec_codes", "n_mcs", "fft_len"}
 PTRS = ["occ_len", "occ", "pilot_carriers", "pilot_symbols", "sync_word1", "sync_word2", "mcs_snr", "mcs_cnst", "mcs_fec"]
 ODD_INTS = [0, -1, 1, 2, 3, 7, 48, 63, 65, 100, 4096, 1 << 20, (1 << 31) - 1, -(1 << 31)]
 ODD_FLOATS = [0.0, -1.0, 1.0, 2.0, 1e30, -1e30, float("nan"), float("inf"), 1e-30]
@@ -44,6 +45,12 @@ for seed in range(first, last):
         did.append("kind %%d" %% kind)
         if kind == 0:
             f, v = rng.choice(INTS), rng.choice(ODD_INTS)
+            if f in COUNTS:
+                # a count says how far the library may read through the caller's arrays: a value between the truth and the
+                # library's own limit would make it read memory the caller never had (the caller's fault, and a sanitizer's
+                # finding) -- so a count is mutated DOWN, or to something the shape check must refuse
+                v = rng.choice([0, -1, 1, (1 << 20), (1 << 31) - 1, -(1 << 31)])
+                v = v if v <= 0 or v >= (1 << 20) else min(v, getattr(c, f))
             did[-1] = "%%s = %%d" %% (f, v)
             setattr(c, f, v)
         elif kind == 1:

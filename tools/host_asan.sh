@@ -18,8 +18,10 @@ RT="$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | h
 cd "$R"
 echo "== product library, host sanitizers"
 DTL_HIP_LIB="$OBJ/libdtl_hip_asan.so" LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
-    python -m pytest tests -q -m "not gpu" -p no:cacheprovider
+    python -m pytest tests -q -m "not gpu" -p no:cacheprovider --deselect tests/test_abi_exceptions_cpu.py
+# (tests/test_abi_exceptions_cpu.py asks for allocations no machine has and expects std::bad_alloc / std::length_error to
+# arrive at the boundary as a status: the sanitizer's allocator aborts on such a request instead of throwing)
 echo "== oracle, sanitizers"
 DTL_ORACLE_LIB="$OBJ/liboracle_asan.so" LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-    ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -q -m "not gpu" -p no:cacheprovider
+    ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -q -m "not gpu" -p no:cacheprovider --deselect tests/test_abi_exceptions_cpu.py
 rm -rf "$OBJ"
