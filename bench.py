@@ -244,12 +244,21 @@ def timed_steps(rx, x, steps, warmup, barrier, pipelined=False):
     """W untimed + exactly K timed passes of the receive path; -> (elapsed s, last result, mean decoder-kernel ms,
     mean payload-kernel ms, summed host stage ms).
     pipelined: the K batches go through dtl_rx_submit / dtl_rx_wait -- batch k+1 is handed over before batch k is waited
-    for, so its sync kernels are queued behind batch k's last kernel and run while the host finishes batch k (records,
-    this loop).  Every batch is decoded completely inside the timed region; results are those of work()."""
+    for, so two batches are in flight on the handle's two lanes.  Every batch is decoded completely inside the timed
+    region; results are those of work()."""
     res = None
     ldpc_ms, payload_ms, stage = [], [], np.zeros(8)
-    for _ in range(warmup):
-        res = rx.work(x, copy_outputs=False)
+    if pipelined and warmup:
+        # the untimed passes go the way the timed ones go -- both lanes of the handle get their buffers and tables
+        n_w = max(warmup, 4)
+        rx.submit(x)
+        for i in range(n_w):
+            if i + 1 < n_w:
+                rx.submit(x)
+            res = rx.wait(copy_outputs=False)
+    else:
+        for _ in range(warmup):
+            res = rx.work(x, copy_outputs=False)
     barrier()
     t0 = time.perf_counter()
     if pipelined:
@@ -339,50 +348,8 @@ def workload_record(dtl, name, device, steps, barrier, arith, seed):
            "roofline": roofline_of(split, bps * x.numel()), "stats": st}
     if st["crc_ok_frac"] < w["min_crc_ok_frac"]:
         rec["error"] = "only %.1f %% of the transport blocks pass their CRC-32 at this operating point" % (100 * st["crc_ok_frac"])
-    rec["two_handles"] = two_handles_record(dtl, cfg, x, max(steps, 10, int(150.0 / max(ms, 1e-3))), res.n_payload_bytes)   # (>= 150 ms of work per thread)
     del x, res, rx
     return rec
-
-
-def two_handles_record(dtl, cfg, x, steps, want_bytes):
-    """Two receiver handles, each on its own host thread and stream, decoding the same resident batch `steps` times: how a
-    host with several independent captures per GPU runs them.  The threads call the C ABI directly (ctypes releases the
-    interpreter lock for the call and nothing of the result is marshalled in Python -- through ofdm_receiver.work() the two
-    would take turns at the interpreter and show no overlap).  One handle's device idle (host round trips at the front of a
-    step, launch gaps) is the other's working time; reported per batch, never instead of the single-handle figure."""
-    import ctypes as C
-    import threading
-    import torch
-    from gr_dtl_amd import _lib
-    from gr_dtl_amd.ofdm_receiver import _Result
-    L = _lib.lib()
-    n_thr = 2
-    rxs = [dtl.ofdm_receiver(cfg) for _ in range(n_thr)]
-    streams = [torch.cuda.Stream() for _ in range(n_thr)]
-    out = [None] * n_thr
-    gate = threading.Barrier(n_thr + 1)
-
-    def run(i):
-        res = _Result()
-        sp = C.c_void_p(streams[i].cuda_stream)
-        rc = 0
-        for _ in range(2):
-            rc |= L.dtl_rx_process(rxs[i]._h, x.data_ptr(), x.numel(), 0, sp, C.byref(res))
-        gate.wait()
-        for _ in range(steps):
-            rc |= L.dtl_rx_process(rxs[i]._h, x.data_ptr(), x.numel(), 0, sp, C.byref(res))
-        out[i] = (rc, int(res.n_payload_bytes))
-    th = [threading.Thread(target=run, args=(i,)) for i in range(n_thr)]
-    for t in th:
-        t.start()
-    gate.wait()
-    t0 = time.perf_counter()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    ok = all(o is not None and o[0] == 0 and o[1] == int(want_bytes) for o in out)
-    return {"handles": n_thr, "ms_per_batch": round(dt / (n_thr * steps) * 1e3, 3),
-            "value": round(n_thr * steps * x.numel() / dt / 1e6, 3), "unit": "Msamples/s", "results_equal_single_handle": bool(ok)}
 
 
 def host_fed_run(rx, host, sl, bufs, copy_stream, out_host=None, timeline=None, out_stream=None):
@@ -719,8 +686,6 @@ def main():
         e0, tot0 = combine(e0, [n_samples], dist, cdev)
         extras["plain_calls"] = {"ms_per_step": round(e0 / args.steps * 1e3, 3), "value": round(float(tot0[0]) * args.steps / e0 / 1e6, 3),
                                  "unit": "Msamples/s", "note": "the same steps as plain dtl_rx_process calls (no hand-over ahead)"}
-        if world == 1:
-            extras["two_handles"] = two_handles_record(dtl, cfg, x, max(10, args.steps // 2, int(150.0 / max(ms_per_step, 1e-3))), res.n_payload_bytes)
     if not args.no_extras:
         # (1) the same step in the other arithmetic, on every rank (same input, same barriers, max over ranks)
         cfg2 = build_config(dtl, w)
@@ -794,9 +759,10 @@ def main():
                                           "blocks CRC-ok (DESIGN.md 6).  NOT comparable with round 2's line, which ran the same "
                                           "batch at 18 dB (all frames found, no block decodable: the decoder's worst case): "
                                           "that point is measured in every run -> `comparable_18dB`",
-                       "step": ("one batch through dtl_rx_submit / dtl_rx_wait: batch k+1's sync kernels are queued behind batch k's "
-                                "last kernel, every batch is decoded completely inside the timed region (extra.plain_calls: the "
-                                "same steps as plain dtl_rx_process calls)") if pipelined else "one dtl_rx_process call per batch",
+                       "step": ("one batch through dtl_rx_submit / dtl_rx_wait: two batches are in flight on the handle's two lanes "
+                                "(a receiver, a host thread and a stream each), one's device idle is the other's working time; "
+                                "every batch is decoded completely inside the timed region, results bit-identical to dtl_rx_process "
+                                "(extra.plain_calls: the same steps as plain dtl_rx_process calls, one batch at a time)") if pipelined else "one dtl_rx_process call per batch",
                        "parallelism": "frame-batch shard per GPU (dp%d), no data-path collective" % world},
             "roofline": roof,
             "stats": st,

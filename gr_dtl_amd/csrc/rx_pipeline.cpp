@@ -710,11 +710,9 @@ int Receiver::kernel_times(int back, double* ldpc_ms, double* payload_ms)
 
 Receiver::~Receiver()
 {
-    if (!queue_.empty()) (void)hipDeviceSynchronize();   // a queued batch's sync kernels may still be running on our buffers
     for (auto& slot : ev_ring_) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     for (auto& e : chunk_ev_) if (e) (void)hipEventDestroy(e);
     if (ev_stats_) (void)hipEventDestroy(ev_stats_);
-    if (ev_done_) (void)hipEventDestroy(ev_done_);
     for (auto& e : angle_ev_) if (e) (void)hipEventDestroy(e);
     for (auto& e : hdr_ev_) if (e) (void)hipEventDestroy(e);
     if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
@@ -1029,7 +1027,6 @@ struct Receiver::Call {
     // entries copied to the pinned edge buffer together with the range's counter
     struct Range { int64_t mb, me; unsigned max_edges, guess; size_t off; };
     std::vector<Range> rg;
-    bool sync_launched = false;   // sync_launch has run for this call (possibly ahead of time: Receiver::submit)
     void lap(const char* what)
     {
         if (!dbg) return;
@@ -1039,14 +1036,6 @@ struct Receiver::Call {
     }
 };
 
-// a batch handed over by submit(); `call` exists once its sync kernels have been queued ahead of time
-struct Receiver::Queued {
-    const cf32* d_iq;
-    int64_t n;
-    unsigned flags;
-    hipStream_t st;
-    std::unique_ptr<Call> call;
-};
 
 // the stages were written as one function; they keep its local names through these aliases
 #define RX_CALL_LOCALS(c)                                                                                       \
@@ -1090,15 +1079,10 @@ int Receiver::stream_begin(Call& c)
 }
 
 // K1, device half: the sync kernel over the call's new samples in up to `sync_ranges_` sample ranges, each with its own
-// device -> host copy of the crossings and an event, all queued at once.  Needs nothing of the stream state beyond what
-// stream_begin has fixed (working buffer, A, B, E): for a self-contained batch it can run before the call itself starts
-// (Receiver::submit -- behind the previous batch's last kernel, so that the device goes on while the host finishes that
-// batch).
+// device -> host copy of the crossings and an event, all queued at once.
 int Receiver::sync_launch(Call& c)
 {
     RX_CALL_LOCALS(c);
-    if (c.sync_launched) return DTL_OK;
-    c.sync_launched = true;
     const int64_t mb0 = B - A;
     // several ranges: what the host does for a range (sort, plateau detector, frame_detect_bb walk, oscillator phases,
     // queueing the range's header kernel) runs while the device is busy with the next range's sync kernel and the
@@ -2091,18 +2075,7 @@ int Receiver::stage_blocks(Call& c)
             tbs[size_t(tix)] = ti;
         }
     }
-    // everything of this batch is queued: the next batch of submit() starts behind it (its sync kernels run while the host
-    // waits here and builds this batch's records)
-    // (the host then waits for THIS batch's last operation -- an event --, not for the stream, which now also holds the next
-    // batch's kernels)
-    if (!queue_.empty() && !queue_.front()->call && queue_.front()->st == st) {
-        if (!ev_done_) DTL_HIP_CHECK(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
-        DTL_HIP_CHECK(hipEventRecord(ev_done_, st));
-        (void)prelaunch(*queue_.front());
-        DTL_HIP_CHECK(hipEventSynchronize(ev_done_));
-    } else {
-        DTL_HIP_CHECK(hipStreamSynchronize(st));
-    }
+    DTL_HIP_CHECK(hipStreamSynchronize(st));
     if (kc_.on) DTL_TRY(kc_.collect());
     if (cfg.has_fec && n_tbs) std::memcpy(tb_res.data(), h_tbres_.p, size_t(n_tbs) * sizeof(TbResult));
     if (!cfg.has_fec && n_frames) std::memcpy(nofec_info.data(), h_nofec_.p, size_t(n_frames) * 8);
@@ -2224,53 +2197,7 @@ int Receiver::process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool f
     return process_stream_body(d_iq, n, flags, final, st);
 }
 
-int Receiver::submit(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t st)
-{
-    if (n < 0 || (!d_iq && n > 0)) { set_last_error("submit: bad input"); return DTL_ERR_INVALID_ARG; }
-    if (n > int64_t(0x7fffffff)) { set_last_error("submit: at most 2^31-1 samples per batch"); return DTL_ERR_INVALID_ARG; }
-    if (queue_.size() >= 2) { set_last_error("submit: two batches are queued already (dtl_rx_wait takes the oldest)"); return DTL_ERR_CAPACITY; }
-    queue_.push_back(std::unique_ptr<Queued>(new Queued{ d_iq, n, flags, st, nullptr }));
-    // nothing is running between two calls on a handle: the only queued batch can start now (its sync kernels go out; a
-    // second one is started by the batch in front of it, behind that batch's last kernel -- stage_blocks)
-    if (queue_.size() == 1) (void)prelaunch(*queue_.front());
-    return DTL_OK;
-}
-
-// the sync kernels of a queued batch, ahead of its wait(): only what a fresh stream fixes without looking at the stream
-// state (no carried samples: A = B = 0).  Any failure leaves the batch to start normally inside wait().
-int Receiver::prelaunch(Queued& q)
-{
-    if (q.call || q.n <= 0 || (q.flags & (RX_WANT_METRIC | RX_WANT_KERNEL_SPLIT))) return DTL_OK;
-    if (cfg.has_fec && decoders_.size() < 2) return DTL_OK;             // (reported by the call itself)
-    DeviceScope dev;
-    if (dev.enter(cfg.device) != DTL_OK) return DTL_OK;
-    if (!uploaded_ && upload_tables() != DTL_OK) return DTL_OK;
-    auto c = std::make_unique<Call>();
-    c->d_iq = q.d_iq; c->iq = q.d_iq; c->n = q.n; c->W = q.n; c->flags = q.flags; c->final = true; c->st = q.st;
-    c->A = 0; c->B = 0; c->E = q.n;
-    c->N = cfg.fft_len; c->cp = cfg.cp_len; c->P = c->N + c->cp; c->h = cfg.header_len(); c->L = cfg.frame_length;
-    c->hdr_syms = 2 + c->h;
-    const bool was_on = kc_.on;
-    kc_.on = false;                                                     // (this launch belongs to no call's kernel clock)
-    const int rc = sync_launch(*c);
-    kc_.on = was_on;
-    if (rc == DTL_OK) q.call = std::move(c);
-    return DTL_OK;
-}
-
-int Receiver::wait(unsigned* flags_out)
-{
-    if (queue_.empty()) { set_last_error("wait: no batch is queued (dtl_rx_submit first)"); return DTL_ERR_INVALID_ARG; }
-    Queued q = std::move(*queue_.front());
-    queue_.erase(queue_.begin());
-    if (flags_out) *flags_out = q.flags;
-    DeviceScope dev;
-    DTL_TRY(dev.enter(cfg.device));
-    reset_stream();
-    return process_stream_body(q.d_iq, q.n, q.flags, true, q.st, std::move(q.call));
-}
-
-int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st, std::unique_ptr<Call> started)
+int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t st)
 {
     StreamState& ss = *ss_;
     struct ResetOnExit { // a failed or final call ends the stream
@@ -2299,8 +2226,7 @@ int Receiver::process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, b
         ev_mask_[slot] = 0;
     }
     kc_.begin((flags & RX_WANT_KERNEL_SPLIT) != 0);
-    // (a batch of submit() arrives with its sync kernels already queued: the same Call goes on)
-    std::unique_ptr<Call> own = started && started->n == n && started->d_iq == d_iq && !ss.carry_len ? std::move(started) : std::make_unique<Call>();
+    auto own = std::make_unique<Call>();
     Call& c = *own;
     c.d_iq = d_iq; c.iq = d_iq; c.n = n; c.W = W; c.flags = flags; c.final = final; c.st = st;
     // A = absolute index of the working buffer's first sample (a multiple of the sync kernel's tile, so that

@@ -183,14 +183,6 @@ public:
     // way process() treats the end of its batch and resets the state.
     int process_stream(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream);
     void reset_stream() noexcept;
-    // Software pipeline over self-contained batches: submit() queues a batch (at most two wait), wait() runs the oldest one
-    // to its end -- the same result as process() on it.  While a batch is finishing (its last kernels are queued, the host
-    // waits for them and builds the records) the NEXT queued batch's sync kernels are already behind them on the stream:
-    // the device does not idle between two batches.  The batch's samples must stay valid and unchanged from submit() to
-    // the wait() that returns its result.
-    int submit(const cf32* d_iq, int64_t n, unsigned flags, hipStream_t stream);
-    int wait(unsigned* flags_out);
-    int queued() const { return int(queue_.size()); }
     int64_t stream_position() const; // samples consumed since the last reset
     // device time of the phase-B kernels and of the LDPC kernel(s) of the call `back` calls ago (0 = the last one), from
     // HIP events recorded on that call's stream; -1 where the call had none
@@ -229,13 +221,10 @@ private:
     struct Call;
     class Worker;
     std::unique_ptr<StreamState> ss_;
-    struct Queued;
-    std::vector<std::unique_ptr<Queued>> queue_;   // batches handed over by submit(), oldest first
-    int prelaunch(Queued& q);
     KernelClock kc_;
     std::unique_ptr<Worker> worker_;  // the sync stage's helper thread: started at the first call that needs it, kept
     bool worker_failed_ = false;      // ... it could not be started: the sync stage runs on the caller's thread alone
-    int process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream, std::unique_ptr<Call> started = nullptr);
+    int process_stream_body(const cf32* d_iq, int64_t n, unsigned flags, bool final, hipStream_t stream);
     int stream_begin(Call& c);
     int sync_launch(Call& c);
     int stage_sync(Call& c);
@@ -267,7 +256,6 @@ private:
     DevBuf d_work_, d_carry_, d_llr_carry_;
     std::vector<hipEvent_t> chunk_ev_; // one per candidate chunk of the phase A/B pipeline
     hipEvent_t ev_stats_ = nullptr;    // the per-frame SNR estimates have reached the host
-    hipEvent_t ev_done_ = nullptr;     // a batch's last operation (the next batch of submit() is queued behind it)
     hipEvent_t ev_pre_ = nullptr;      // the decoder's preparations on the side stream (stage_blocks)
     hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
     std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers

@@ -447,11 +447,15 @@ class ofdm_receiver:
         return iq.contiguous().view(-1), flags
 
     def submit(self, iq, want=()):
-        """work() in two halves (dtl_rx_submit / dtl_rx_wait): queue a self-contained batch -- at most two may wait.  While
-        the batch in front of it finishes, this one's sync kernels already run.  `iq` is kept alive until its wait()."""
+        """work() in two halves (dtl_rx_submit / dtl_rx_wait): hand over a self-contained batch -- at most two may wait.  The
+        two run side by side (two lanes inside the handle: a receiver, a host thread and a stream each), one's device idle
+        is the other's working time.  `iq` is kept alive until its wait()."""
         iq, flags = self._check_input(iq, want)
         if not hasattr(self, "_submitted"):
             self._submitted = []
+        # the records of the last result are read from the library's own arrays on first use: a batch handed over now may
+        # run on the lane that produced them and overwrite them -- take them first
+        self._settle_last_result()
         _lib.check(_lib.lib().dtl_rx_submit(self._h, iq.data_ptr(), iq.numel(), flags, _lib.current_stream_ptr()))
         self._submitted.append((iq, tuple(want)))
 

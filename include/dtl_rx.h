@@ -228,16 +228,20 @@ int dtl_rx_process(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t fla
 int dtl_rx_process_stream(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t flags, int32_t final,
                           void* stream, dtl_rx_result* out);
 /* dtl_rx_process in two halves, for callers that decode batch after batch: dtl_rx_submit hands a self-contained batch
- * over (at most two may be waiting), dtl_rx_wait runs the oldest one to its end and returns what dtl_rx_process would.
+ * over and returns at once (at most two may be waiting), dtl_rx_wait returns the oldest one's result -- what
+ * dtl_rx_process would have returned for it, bit for bit.
  *     submit(b0); submit(b1); wait -> r0; submit(b2); wait -> r1; ...
- * While batch k finishes -- its last kernels are queued, the host waits for them and builds the records -- the sync kernels
- * of batch k + 1 are already behind them on the stream: the device does not idle between two batches (dtl_rx_process
- * leaves it idle for the host's epilogue, the caller's own work and the next call's first launches).  d_iq must stay
- * valid and unchanged from dtl_rx_submit to the dtl_rx_wait that returns the batch's result; results are bit-identical
- * to dtl_rx_process on the same batch.  DTL_ERR_CAPACITY: two batches are queued already.  Not to be mixed with a
- * running stream (dtl_rx_process_stream without final): every wait starts from a reset, like dtl_rx_process.
- * Overlaps, in the reference's terms, the work() of ofdm_sync_sc_cfb on the next buffer with the FEC decoder's work() on
- * the previous one (python/dtl/ofdm_receiver.py:71-98 vs :196-211) -- there, separate scheduler threads do that. */
+ * The two batches in flight run side by side on two LANES inside the handle (each a receiver with the handle's
+ * configuration, a host thread and a stream of its own; the second is made at the first submit that needs it and doubles the
+ * handle's device memory): where one's step leaves the device idle -- the host round trips at its front, launch gaps, the
+ * decoder's tail -- the other's kernels run.  In the reference's terms this is what GNU Radio's scheduler does by
+ * running every block in its own thread: ofdm_sync_sc_cfb works on the next buffer while the FEC decoder works on the
+ * previous one (python/dtl/ofdm_receiver.py:71-98 vs :196-211).
+ * `stream`: the lane's work starts behind whatever the caller has queued there at submit; d_iq must stay valid and
+ * unchanged until the dtl_rx_wait that returns the batch.  A result (host arrays and device buffers) stays valid until the
+ * SECOND dtl_rx_submit after its dtl_rx_wait (the lane that produced it is reused then).  DTL_ERR_CAPACITY: two batches
+ * are waiting already.  Not to be mixed with a running stream (dtl_rx_process_stream without final) -- plain calls are
+ * refused while batches wait -- and every batch starts from a reset, like dtl_rx_process. */
 int dtl_rx_submit(dtl_rx* h, const float* d_iq, int64_t n_samples, uint32_t flags, void* stream);
 int dtl_rx_wait(dtl_rx* h, dtl_rx_result* out);
 void dtl_rx_reset(dtl_rx* h);

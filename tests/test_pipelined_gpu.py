@@ -112,8 +112,8 @@ def _same_result(a, b):
 @pytest.mark.gpu
 @pytest.mark.parametrize("split", [False, True])
 def test_submit_wait_equals_work_batch_by_batch(oracle, dtl, cuda, monkeypatch, split):
-    """dtl_rx_submit / dtl_rx_wait (the next batch's sync kernels are queued behind the running batch's last kernel): five
-    different batches through the two-deep queue return, one by one, exactly what work() returns for each -- triggers,
+    """dtl_rx_submit / dtl_rx_wait (two batches in flight on the handle's two lanes -- two receivers, two host threads, two
+    streams): five different batches through the two-deep queue return, one by one, exactly what work() returns for each -- triggers,
     frame records, block records, soft bits and bytes -- with the single-range and the four-range sync stage."""
     import torch
     if split:
@@ -188,3 +188,49 @@ def test_handle_bound_to_a_device(oracle, dtl, cuda):
         far.work(xt)
     assert e.value.code in (_lib.ERR_HIP, _lib.ERR_INVALID_ARG, _lib.ERR_NO_DEVICE), e.value
     assert bound.work(xt).n_payload_bytes == want.n_payload_bytes          # the failed handle disturbed nobody
+
+
+@pytest.mark.gpu
+def test_a_lanes_failure_arrives_at_wait_with_its_text(oracle, dtl, cuda):
+    """A batch that fails on its lane's thread: dtl_rx_wait returns the status and dtl_last_error() the text (which the
+    library keeps per thread), for both lanes; the handle's queue is empty afterwards."""
+    import torch
+    from gr_dtl_amd import _lib
+    pcfg = dtl.ofdm_adaptive_rx_config(frame_length=4)
+    pcfg.occupied_carriers = (tuple(pcfg.occupied_carriers[0])[4:-4],)        # 96 header bits do not fit: refused at the call
+    pcfg.fec_codes = (("fec_1", "n_0300_k_0152_gap_03.alist"),)
+    pcfg.mcs = ((-100000, (dtl.constellation_type_t.BPSK, "fec_1")),)
+    rx = dtl.ofdm_receiver(pcfg)
+    x = torch.zeros(5000, dtype=torch.complex64, device=cuda)
+    rx.submit(x)
+    rx.submit(x)
+    for _ in range(2):
+        with pytest.raises(_lib.DtlError) as e:
+            rx.wait()
+        assert e.value.code == _lib.ERR_INVALID_ARG and "header" in str(e.value)
+    with pytest.raises(_lib.DtlError) as e:
+        rx.wait()
+    assert "no batch" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_many_batches_through_both_lanes_in_order(oracle, dtl, cuda):
+    """Twelve batches of three kinds through the two lanes, two always in flight: every result is its own batch's (the
+    order of wait() is the order of submit()), whichever lane and however long a batch takes."""
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=64, sync_threshold=0.95)
+    kinds = []
+    for i, (cnst, esn0, nb) in enumerate([(2, 13.0, 30000), (4, 24.0, 3000), (1, 20.0, 9000)]):    # long, short, middle
+        user, hdrs, x = make_stream(oracle, ocfg, code, cnst, nb, esn0, seed=900 + i)
+        xt = torch.from_numpy(x).to(cuda)
+        kinds.append((xt, dtl.ofdm_receiver(pcfg).work(xt)))
+    order = [0, 1, 1, 2, 0, 0, 2, 1, 2, 2, 0, 1]
+    rx = dtl.ofdm_receiver(pcfg)
+    got = []
+    rx.submit(kinds[order[0]][0])
+    for j in range(len(order)):
+        if j + 1 < len(order):
+            rx.submit(kinds[order[j + 1]][0])
+        got.append(rx.wait())
+    for j, r in enumerate(got):
+        _same_result(r, kinds[order[j]][1])
