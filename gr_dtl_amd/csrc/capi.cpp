@@ -109,6 +109,7 @@ struct RxLane {
 };
 
 struct dtl_rx {
+    dtl::DecoderGate gate;                    // the lanes' decoders take turns on the device (declared first: outlives the receivers)
     dtl::Receiver rx;
     // dtl_rx_submit / dtl_rx_wait
     std::unique_ptr<RxLane> lane[2];
@@ -480,10 +481,11 @@ int dtl_rx_submit(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void*
     DTL_TRY(dev.enter(h->rx.cfg.device));
     if (!h->lane[ln]) {
         auto L = std::make_unique<RxLane>();
-        if (ln == 0) L->r = &h->rx;
+        if (ln == 0) { L->r = &h->rx; h->rx.decoder_gate = &h->gate; }
         else {
             L->own = std::make_unique<dtl::Receiver>();
             L->own->cfg = h->rx.cfg;
+            L->own->decoder_gate = &h->gate;
             DTL_TRY(L->own->init());
             L->r = L->own.get();
         }

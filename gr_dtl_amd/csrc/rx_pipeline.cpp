@@ -717,6 +717,8 @@ Receiver::~Receiver()
     for (auto& e : hdr_ev_) if (e) (void)hipEventDestroy(e);
     if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
     if (ev_pre_) (void)hipEventDestroy(ev_pre_);
+    if (decoder_gate) { std::lock_guard<std::mutex> lk(decoder_gate->mu); for (hipEvent_t e : ev_dec_) if (decoder_gate->last_done == e) decoder_gate->last_done = nullptr; }
+    for (hipEvent_t e : ev_dec_) if (e) (void)hipEventDestroy(e);
 }
 
 int Receiver::init()
@@ -2015,13 +2017,29 @@ int Receiver::stage_blocks(Call& c)
                 DTL_TRY(launch_llr_gather(d_llrcopy_.as<LlrCopy>(), int(llr_copies.size()), d_llr.as<float>(), st));
             }
             if (ev_) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));
-            for (auto& cr : code_ranges) {
-                KC_BEGIN(st);
-                DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
-                                                    d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st, packed));
-                KC_END(KernelClock::LDPC, st);
+            {
+                // (several receivers on this device: decoders one after the other -- DecoderGate; the lock covers the launch
+                // only, the dependency is the device's business)
+                std::unique_lock<std::mutex> gate_lock;
+                if (decoder_gate) {
+                    gate_lock = std::unique_lock<std::mutex>(decoder_gate->mu);
+                    if (decoder_gate->last_done) DTL_HIP_CHECK(hipStreamWaitEvent(st, decoder_gate->last_done, 0));
+                    if (ev_) DTL_HIP_CHECK(hipEventRecord(ev_[2], st));   // (the decoder's start, behind the wait)
+                }
+                for (auto& cr : code_ranges) {
+                    KC_BEGIN(st);
+                    DTL_TRY(decoders_[cr.first]->decode(d_llr.as<float>(), d_cwdesc_.as<CwDesc>() + cr.second.first, cr.second.second,
+                                                        d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>() + cr.second.first, st, packed));
+                    KC_END(KernelClock::LDPC, st);
+                }
+                if (ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[3], st)); ev_mask_[(n_calls_ - 1) % kEvRing] |= 2u; }
+                if (decoder_gate) {
+                    hipEvent_t& mine = ev_dec_[dec_launches_++ & 1u];
+                    if (!mine) DTL_HIP_CHECK(hipEventCreateWithFlags(&mine, hipEventDisableTiming));
+                    DTL_HIP_CHECK(hipEventRecord(mine, st));
+                    decoder_gate->last_done = mine;
+                }
             }
-            if (ev_) { DTL_HIP_CHECK(hipEventRecord(ev_[3], st)); ev_mask_[(n_calls_ - 1) % kEvRing] |= 2u; }
             DTL_TRY(d_payload.ensure(max_out_bytes + 64));
             KC_BEGIN(st);
             DTL_TRY(launch_tb_check(d_tbgather_.as<TbGather>(), n_tbs, d_cw_bits.as<uint8_t>(), d_cw_nit.as<int32_t>(),

@@ -9,6 +9,7 @@
 #include "rx_types.h"
 
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -169,9 +170,19 @@ struct KernelClock {
     int collect();                                 // behind the call's last synchronisation
 };
 
+// Two receivers that share one device (the lanes of dtl_rx_submit) take turns at the decoder: its 256 persistent workgroups
+// fill every CU's LDS, so a second decoder launched next to it only waits inside the device for the first one's workgroups to
+// leave -- and its measured duration would count that wait.  The later launch is made to wait for the earlier one's end
+// explicitly (an event dependency in front of its own timing events).
+struct DecoderGate {
+    std::mutex mu;
+    hipEvent_t last_done = nullptr;          // end of the decoder launched last (owned by the receiver that recorded it)
+};
+
 class Receiver {
 public:
     RxConfig cfg;
+    DecoderGate* decoder_gate = nullptr;     // set by the owner of several receivers on one device (capi.cpp: the lanes)
     Receiver();
     ~Receiver();
     int init(); // validate, derive tables, parse codes (no GPU needed)
@@ -257,6 +268,8 @@ private:
     std::vector<hipEvent_t> chunk_ev_; // one per candidate chunk of the phase A/B pipeline
     hipEvent_t ev_stats_ = nullptr;    // the per-frame SNR estimates have reached the host
     hipEvent_t ev_pre_ = nullptr;      // the decoder's preparations on the side stream (stage_blocks)
+    hipEvent_t ev_dec_[2] = { nullptr, nullptr };   // ends of this receiver's last two decoder launches (DecoderGate)
+    unsigned dec_launches_ = 0;
     hipStream_t side_ = nullptr;       // arg(P) at the triggers of one sample range while the sync kernel runs on the next
     std::vector<hipEvent_t> angle_ev_; // one per submitted group of triggers
     std::vector<hipEvent_t> hdr_ev_;   // one per header-kernel launch of a call

@@ -18,7 +18,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o c3 -- python3 
 echo "WRITE_SIZE pass done"
 python3 "$R/bench.py" --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 "$R/tools/pmc_traffic.py" "$OUT" "$TAG" c3
-KT="$(find "$OUT/stats" -name '*kernel_trace.csv' | head -1)"
+# the device timeline of ONE call: a trace of plain calls (with two batches in flight on the handle's lanes -- the bench's
+# default -- the kernels of two steps interleave and no step can be cut out of the trace)
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_plain" -o c3 -- python3 "$R/bench.py" --steps 5 --warmup 2 --headline-only --no-pipeline > "$OUT/trace_plain.json" 2> "$OUT/trace_plain.err"
+KT="$(find "$OUT/trace_plain" -name '*kernel_trace.csv' | head -1)"
 if [[ -n "$KT" ]]; then python3 "$R/tools/timeline.py" "$KT" > "$OUT/summary/c3_timeline.txt" || true; fi
 find "$OUT" -name "*.csv" -size +20M -delete   # raw per-dispatch counter dumps can be large
 ls -la "$OUT" "$OUT"/*
