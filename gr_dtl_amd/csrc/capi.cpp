@@ -61,6 +61,7 @@ struct RxLane {
     const dtl::cf32* iq = nullptr;
     int64_t n = 0;
     unsigned flags = 0;
+    int device = 0;                          // the device of the lane's stream and buffers
     int rc = DTL_OK;
     char err[512] = "";
     void loop()
@@ -73,8 +74,9 @@ struct RxLane {
                 has_job = false;
             }
             int code = ::dtl::guarded("dtl_rx_submit (lane)", [&]() -> int {
-                ::dtl::DeviceScope dev;
-                DTL_TRY(dev.enter(r->cfg.device));
+                // (a new thread starts on device 0: the batch runs on the device that was current for the caller at submit --
+                // one process per GPU sets it per rank -- unless the handle is bound to one, dtl_rx_cfg.device)
+                DTL_HIP_CHECK(hipSetDevice(device));
                 DTL_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
                 return r->process(iq, n, flags, st);
             });
@@ -479,8 +481,15 @@ int dtl_rx_submit(dtl_rx* h, const float* d_iq, int64_t n, uint32_t flags, void*
     if (h->lane[ln] && h->lane[ln]->busy) ln ^= 1;                // (fewer than two are waiting: the other lane is free)
     dtl::DeviceScope dev;
     DTL_TRY(dev.enter(h->rx.cfg.device));
+    int device = 0;
+    DTL_HIP_CHECK(hipGetDevice(&device));                         // the handle's device, or the caller's current one
+    if (h->lane[ln] && h->lane[ln]->device != device) {
+        dtl::set_last_error("submit: the handle's lanes were made on another device (bind the handle: dtl_rx_cfg.device)");
+        return DTL_ERR_INVALID_ARG;
+    }
     if (!h->lane[ln]) {
         auto L = std::make_unique<RxLane>();
+        L->device = device;
         if (ln == 0) { L->r = &h->rx; h->rx.decoder_gate = &h->gate; }
         else {
             L->own = std::make_unique<dtl::Receiver>();
