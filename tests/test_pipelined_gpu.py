@@ -234,3 +234,55 @@ def test_many_batches_through_both_lanes_in_order(oracle, dtl, cuda):
         got.append(rx.wait())
     for j, r in enumerate(got):
         _same_result(r, kinds[order[j]][1])
+
+
+@pytest.mark.gpu
+def test_lanes_under_a_random_schedule(oracle, dtl, cuda):
+    """400 operations drawn at random -- submit (when fewer than two wait), wait, a plain call when nothing waits, now and
+    then a new handle while the old one still has batches waiting -- against the byte counts and block records each batch
+    has on its own: no deadlock, no result of another batch, no state carried from a batch into the next."""
+    import torch
+    pcfg, ocfg, code = make_pair(oracle, dtl, fft_len=64, sync_threshold=0.95)
+    kinds = []
+    for i, (cnst, esn0, nb) in enumerate([(2, 13.0, 6000), (4, 24.0, 2000), (1, 20.0, 500), (3, 21.0, 3000)]):
+        user, hdrs, x = make_stream(oracle, ocfg, code, cnst, nb, esn0, seed=1300 + i)
+        xt = torch.from_numpy(x).to(cuda)
+        r = dtl.ofdm_receiver(pcfg).work(xt)
+        kinds.append((xt, r.n_payload_bytes, [(int(t["tb_no"]), int(t["crc_ok"])) for t in r.tbs], r.payload.cpu().numpy()))
+    kinds.append((kinds[0][0][:0], 0, [], np.zeros(0, np.uint8)))                      # an empty batch
+    rng = np.random.default_rng(44)
+    rx = dtl.ofdm_receiver(pcfg)
+    waiting = []
+    checked = 0
+    log = []
+    for step in range(400):
+        op = rng.random()
+        if op < 0.02:
+            rx = dtl.ofdm_receiver(pcfg)              # the old handle goes away with whatever it still had
+            waiting = []
+            log.append("new")
+            continue
+        elif (op < 0.55 and len(waiting) < 2) or not waiting:
+            if not waiting and op > 0.9:
+                k = int(rng.integers(len(kinds)))
+                r = rx.work(kinds[k][0])
+                log.append("work%d" % k)
+            else:
+                k = int(rng.integers(len(kinds)))
+                rx.submit(kinds[k][0])
+                waiting.append(k)
+                log.append("sub%d" % k)
+                continue
+        else:
+            k = waiting.pop(0)
+            r = rx.wait()
+            log.append("wait%d" % k)
+        assert r.n_payload_bytes == kinds[k][1], (step, k, " ".join(log[-14:]))
+        assert [(int(t["tb_no"]), int(t["crc_ok"])) for t in r.tbs] == kinds[k][2], (step, k)
+        if step % 7 == 0:
+            np.testing.assert_array_equal(r.payload.cpu().numpy(), kinds[k][3])
+        checked += 1
+    assert checked > 150
+    while waiting:
+        k = waiting.pop(0)
+        assert rx.wait().n_payload_bytes == kinds[k][1]
