@@ -1,6 +1,6 @@
 // C++ host program over the C ABI alone (include/dtl_rx.h + the HIP runtime, no Python): build an
 // ofdm_adaptive_config equivalent, generate frames with dtl_tx_*, decode them with dtl_rx_process and
-// again in three arbitrary slices with dtl_rx_process_stream; the user bytes must come back.
+// again in three arbitrary slices with dtl_rx_process_stream, and through dtl_rx_submit / dtl_rx_wait; the user bytes must come back.
 // usage: test_rx_loopback <alist file> <constellation 1..4> <user bytes>
 #include <dtl_rx.h>
 #include <hip/hip_runtime.h>
@@ -97,6 +97,26 @@ int main(int argc, char** argv)
         got2.insert(got2.end(), part.begin(), part.end());
     }
     if (got2 != user) { std::fprintf(stderr, "stream: %zu bytes back, %zu sent\n", got2.size(), user.size()); return 5; }
+
+    // batches handed over ahead: four submits through the handle's two lanes, two always in flight, results in order
+    // (the whole stream, its first half, the whole stream, nothing)
+    {
+        const int64_t len[4] = { n, n / 2, n, 0 };
+        size_t bytes[4] = { 0, 0, 0, 0 };
+        CHECK_DTL(dtl_rx_submit(rx, d_x, len[0], 0, nullptr));
+        for (int i = 0; i < 4; i++) {
+            if (i + 1 < 4) CHECK_DTL(dtl_rx_submit(rx, d_x, len[i + 1], 0, nullptr));
+            CHECK_DTL(dtl_rx_wait(rx, &r));
+            bytes[i] = size_t(r.n_payload_bytes);
+            if (i == 0 || i == 2) {
+                std::vector<uint8_t> g(bytes[i]);
+                if (!g.empty()) CHECK_HIP(hipMemcpy(g.data(), r.d_payload, g.size(), hipMemcpyDeviceToHost));
+                if (g != user) { std::fprintf(stderr, "submit/wait %d: %zu bytes back, %zu sent\n", i, g.size(), user.size()); return 6; }
+            }
+        }
+        if (!(bytes[1] > 0 && bytes[1] < bytes[0] && bytes[3] == 0)) { std::fprintf(stderr, "submit/wait: %zu %zu %zu %zu\n", bytes[0], bytes[1], bytes[2], bytes[3]); return 7; }
+        if (dtl_rx_wait(rx, &r) != DTL_ERR_INVALID_ARG) { std::fprintf(stderr, "wait on an empty queue must be refused\n"); return 8; }
+    }
     std::printf("OK frames=%lld tbs=%lld bytes=%zu\n", frames, tbs, got.size());
     dtl_rx_destroy(rx);
     dtl_tx_destroy(tx);
