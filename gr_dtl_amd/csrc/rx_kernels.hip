@@ -1617,17 +1617,16 @@ __global__ __launch_bounds__(64) void tb_check_kernel(const TbGather* __restrict
     const int tb = blockIdx.x;
     if (tb >= n_tbs) return;
     const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) {
-        uint32_t c = uint32_t(i);
-        for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-        T[i] = c;
-    }
-    {   // loads in groups without a branch between them: one memory latency per group, not per load
-        uint32_t z[8];
+    {   // the zero-append maps and, behind them, the byte table (both built once on the host: a workgroup that formed its own
+        // 256 entries spent a fifth of its instructions on them); loads in one group without a branch between them: one
+        // memory latency for all twelve
+        uint32_t z[12];
 #pragma unroll
-        for (int j = 0; j < 8; j++) z[j] = zmat_g[lane + 64 * j];
+        for (int j = 0; j < 12; j++) z[j] = zmat_g[lane + 64 * j];
 #pragma unroll
         for (int j = 0; j < 8; j++) zmat[lane + 64 * j] = z[j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) T[lane + 64 * j] = z[8 + j];
     }
     // the block's place in the decoder's output comes from its gather recipe (one table for expand_cw and this kernel)
     const TbDesc d = { tbs[tb].bits_off, uint32_t(tbs[tb].tb_payload), tbs[tb].cw_first, uint32_t(tbs[tb].n_cw) };
@@ -2150,6 +2149,7 @@ int launch_tb_check(const TbGather* tbs, int n_tbs, const uint8_t* bits, const i
                 for (int c = 0; c < 32; c++) if ((v >> c) & 1u) acc ^= z[(j - 1) * 32 + c];
                 z[j * 32 + b] = acc;
             }
+        z.insert(z.end(), T, T + 256);                // the byte table behind the maps (tb_check_kernel reads both)
         uint32_t* p = nullptr;
         DTL_HIP_CHECK(hipMalloc(&p, z.size() * 4));
         DTL_HIP_CHECK(hipMemcpy(p, z.data(), z.size() * 4, hipMemcpyHostToDevice));
