@@ -335,6 +335,9 @@ def workload_record(dtl, name, device, steps, barrier, arith, seed):
     rx = dtl.ofdm_receiver(cfg)
     x, n_frames, n_user, _ = synth_stream(dtl, cfg, w, w["frames"], device, seed=seed)
     torch.cuda.synchronize()
+    # (a batch of a millisecond needs more than a few dozen passes for a stable figure: at least ~150 ms of timed work)
+    probe, _, _, _, _ = timed_steps(rx, x, 4, 4, barrier, pipelined=True)
+    steps = max(steps, min(400, int(0.15 / max(probe / 4, 1e-5))))
     elapsed, res, t_ldpc, t_payload, stage = timed_steps(rx, x, steps, 2, barrier, pipelined=True)
     st = decode_stats(rx, x, res, n_user)
     st["crc_ok_frac"] = round(st["tbs_crc_ok"] / max(1, st["tbs"]), 4)
@@ -342,7 +345,7 @@ def workload_record(dtl, name, device, steps, barrier, arith, seed):
     split = kernel_split(rx, x)
     ms = elapsed / steps * 1e3
     rec = {"workload": w["desc"], "fft_len": w["fft_len"], "frames": n_frames, "samples": int(x.numel()), "esn0_db": w["esn0_db"],
-           "arith": arith, "ms_per_step": round(ms, 3), "value": round(x.numel() * steps / elapsed / 1e6, 3), "unit": "Msamples/s",
+           "arith": arith, "steps": steps, "ms_per_step": round(ms, 3), "value": round(x.numel() * steps / elapsed / 1e6, 3), "unit": "Msamples/s",
            "bytes_per_sample": round(bps, 3), "kernel_sum_ms": round(sum(v["ms"] for v in split.values()), 3),
            "host_stage_ms": [round(float(v) / steps, 3) for v in stage[:6]],
            "roofline": roofline_of(split, bps * x.numel()), "stats": st}
